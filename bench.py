@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LLaDA-8B generate(), gen_length=256, steps=256, block_length=32, synthetic
+prompts (P=128) and random-init weights at the true shapes, data-parallel over N GPUs with a fixed
+number of prompt rows per GPU (weak scaling; 8 rows/GPU = the 64-prompt north-star batch on 8 GPUs).
+
+One "step" = one denoising step of the whole per-GPU batch: the non-causal forward over all
+B*(P+G) tokens plus the fused remasking epilogue.  `value` = generated tokens/s of the whole job =
+N*B*G / (steps_total * time_per_step).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel = the gate/up projection GEMM (SwiGLU epilogue); achieved = its
+                  algorithmic FLOPs per launch / its mean launch duration measured with HIP events
+                  inside the timed region; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline -- the numpy oracle timed on this host on a bounded sample of the same step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def cpu_baseline(B, L, bl, cfg, seconds_hint=20.0):
+    """Oracle (numpy) on the host: ONE transformer layer of the 32 at the full token count, plus the
+    final norm / LM head on the block rows and the remasking epilogue; the step time is
+    extrapolated as 32 * layer + head + epilogue.  kind = "port" (the oracle restates the
+    reference's algorithm; the reference's own model code is not in its tree)."""
+    import numpy as np
+
+    from oracle import sampler as osamp
+    from oracle.model import LLaDAConfig as OCfg
+    from oracle.model import forward, rmsnorm
+    from oracle.bf16 import round_bf16
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    ocfg = OCfg(d_model=cfg.d_model, n_layers=1, n_heads=cfg.n_heads, mlp_hidden=cfg.mlp_hidden, vocab_size=cfg.vocab_size)
+    g = np.random.Generator(np.random.PCG64(0))
+
+    def w(n, k, s=0.02):
+        return round_bf16(g.standard_normal(size=(n, k), dtype=np.float32) * np.float32(s))
+
+    d, F, V = cfg.d_model, cfg.mlp_hidden, cfg.vocab_size
+    # a small embedding table (ids are folded into it) keeps the sample's memory bounded
+    W = {"wte": w(4096, d), "ln_f": np.ones(d, np.float32), "ff_out": w(V, d, 0.16)}
+    p = "blocks.0."
+    for name, shape in (("q_proj", (d, d)), ("k_proj", (d, d)), ("v_proj", (d, d)), ("attn_out", (d, d)),
+                        ("ff_proj", (F, d)), ("up_proj", (F, d)), ("ff_out", (d, F))):
+        W[p + name] = w(*shape)
+    W[p + "attn_norm"] = np.ones(d, np.float32)
+    W[p + "ff_norm"] = np.ones(d, np.float32)
+    ids = g.integers(0, 4096, size=(B, L), dtype=np.int64)
+    t0 = time.perf_counter()
+    h = forward(W, ocfg, ids, None, emulate_bf16=True, return_hidden=True)     # 1 layer + final norm
+    t_layer = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hb = h[:, L - bl:, :].reshape(B * bl, d)
+    logits = round_bf16(hb @ W["ff_out"].T).reshape(B, bl, V)
+    x = np.full((B, bl), cfg.mask_token_id, dtype=np.int64)
+    x0, conf = osamp.confidence_step(x, logits, cfg.mask_token_id, bl, "low_confidence")
+    osamp.topk_transfer(x, x0, conf, np.ones(B, dtype=np.int64))
+    t_head = time.perf_counter() - t0
+    t_step = cfg.n_layers * t_layer + t_head
+    return t_step, cores, (f"1 of {cfg.n_layers} layers at {B}x{L} tokens ({t_layer:.2f} s) + LM head/epilogue on "
+                           f"{B * bl} rows ({t_head:.2f} s); step = {cfg.n_layers}*layer + head")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=8, help="prompt rows per GPU")
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--gen", type=int, default=256)
+    ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers makes the result INVALID")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights, _lib, generate
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    cfg = LLaDAConfig(n_layers=args.layers)
+    model = LLaDAModel(LLaDAWeights.random(cfg, device, seed=0))
+    lib = _lib.load()
+    lib.llada_gemm_profile_begin.restype = C.c_int
+    lib.llada_gemm_profile_begin.argtypes = [C.c_int, C.c_int]
+    lib.llada_gemm_profile_end.restype = C.c_int
+    lib.llada_gemm_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+    B, P, G, bl = args.batch, args.prompt, args.gen, args.block
+    L = P + G
+    steps_total = G                                    # steps == gen_length (best-quality setting)
+    gen = torch.Generator().manual_seed(1234)
+    prompts_all = torch.randint(0, 126000, (world * B, P), generator=gen, dtype=torch.long)
+    prompt = prompts_all[rank * B:(rank + 1) * B]
+
+    W_, K_ = args.warmup, args.steps
+    state = {"n": 0, "t0": None, "t1": None}
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def cb(block, step, x, x0, conf):
+        state["n"] += 1
+        if state["n"] == W_:
+            sync_all()
+            lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers)
+            state["t0"] = time.perf_counter()
+        elif state["n"] == W_ + K_:
+            sync_all()
+            state["t1"] = time.perf_counter()
+
+    if W_ == 0:
+        sync_all()
+        lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers)
+        state["t0"] = time.perf_counter()
+    out = None
+    while state["t1"] is None:
+        out = generate(model, prompt, None, steps=steps_total, gen_length=G, block_length=bl, temperature=0.,
+                       cfg_scale=0., remasking="low_confidence", row_offset=rank * B, step_callback=cb)
+    tot_ms, n_s = C.c_double(0), C.c_int(0)
+    lib.llada_gemm_profile_end(C.byref(tot_ms), C.byref(n_s))
+    torch.cuda.synchronize()
+    elapsed = state["t1"] - state["t0"]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / K_
+    tokens_per_s = world * B * G / (steps_total * ms_per_step * 1e-3)
+
+    if rank == 0:
+        M = B * L
+        F, d, V = cfg.mlp_hidden, cfg.d_model, cfg.vocab_size
+        gemm_flops = 2.0 * M * (2 * F) * d
+        gemm_ms = tot_ms.value / max(n_s.value, 1)
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        lin = cfg.n_layers * (4 * d * d + 3 * d * F)
+        flops_step = 2.0 * M * lin + 2.0 * (B * bl) * d * V + M * 4.0 * L * d * cfg.n_layers
+        rec = {
+            "metric": "generated tokens/sec/node, LLaDA-8B gen256 steps256 blk32; ms/denoise step",
+            "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": K_, "warmup": W_,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"LLaDA-8B generate(): {B} prompts/GPU x P={P}, gen_length={G}, steps={steps_total}, "
+                                   f"block_length={bl}, temperature 0, low_confidence (north-star batch 64 = 8 GPUs x 8)",
+                       "layers": cfg.n_layers, "rows_per_gpu": B, "seq_len": L, "parallelism": f"dp{world}"},
+            "step_tflops_executed": round(flops_step / 1e12, 3),
+            "mfma_util_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<.,SWIGLU> (gate/up projection)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_timed": n_s.value, "avg_launch_ms": round(gemm_ms, 4),
+                         "flops_per_launch": gemm_flops},
+        }
+        if not args.no_cpu_baseline:
+            t_step, cores, sample = cpu_baseline(B, L, bl, cfg)
+            rec["cpu_baseline"] = {"value": round(B * G / (steps_total * t_step), 4), "unit": "tokens/s", "cores": cores,
+                                   "kind": "port", "sample": sample, "ms_per_step": round(1e3 * t_step, 1)}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,207 @@
+// Bidirectional multi-head attention for gfx950, head_dim 128, bf16 in/out, float32 online softmax.
+//
+// Replaces torch's scaled_dot_product_attention(is_causal=False) inside the mask predictor the
+// reference calls at generate.py:88,92 / get_log_likelihood.py:38: every denoising step attends
+// the whole sequence, so there is no causal mask, only an optional key-padding mask
+// (generate.py:63-64).
+//
+// One workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries.
+// Per 64-key tile: S^T = K Q^T on v_mfma_f32_32x32x16_bf16 (keys on the accumulator rows, so a
+// query's scores sit in one lane's registers and the row max/sum need no cross-lane work beyond
+// one half-swap), P is converted to bf16 in registers and used directly as the B operand of
+// O^T += V^T P^T; the V^T fragments come out of the row-major V tile in LDS through the
+// transposing ds_read_b64_tr_b16.  K/V tiles are register-staged: the next tile's global loads
+// are in flight while the current tile is computed.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;
+constexpr int QB = 128;         // queries per workgroup
+constexpr int KT = 64;          // keys per tile
+constexpr int K_STRIDE = 272;   // bytes per K row in LDS: 256 + 16 -> conflict-free ds_read_b128
+constexpr int V_STRIDE = 320;   // bytes per V row in LDS: 256 + 64 -> conflict-free ds_read_b64_tr_b16
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+}
+
+__global__ void __launch_bounds__(256, 2)
+attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out,
+                  int L, int d, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * K_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned char v_lds[KT * V_STRIDE];
+    __shared__ __attribute__((aligned(16))) float bias_lds[KT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hg = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB + wave * 32;
+    const size_t row_stride = (size_t)3 * d;
+    const bf16_t* base = qkv + (size_t)b * L * row_stride + (size_t)h * HD;
+
+    // Q fragments: B operand of S^T = K Q^T, lane holds Q[q0 + r][16*ds + 8*hg .. +7]
+    bf16x8 qf[8];
+    {
+        const int q = min(q0 + r, L - 1);
+        const bf16_t* qp = base + (size_t)q * row_stride + hg * 8;
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 16);
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: thread t moves chunk (t & 15) of keys (t >> 4) + 16*i, i = 0..3, for K and V
+    const int s_key = tid >> 4, s_chunk = tid & 15;
+    u32x4 kreg[4], vreg[4];
+    auto load_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = min(kt0 + s_key + 16 * i, L - 1);
+            const bf16_t* kp = base + (size_t)key * row_stride + d + s_chunk * 8;
+            kreg[i] = *(const u32x4*)kp;
+            vreg[i] = *(const u32x4*)(kp + d);
+        }
+    };
+    auto write_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = s_key + 16 * i;
+            *(u32x4*)(k_lds + key * K_STRIDE + s_chunk * 16) = kreg[i];
+            *(u32x4*)(v_lds + key * V_STRIDE + s_chunk * 16) = vreg[i];
+        }
+        if (tid < KT) {
+            const int key = kt0 + tid;
+            bool ok = key < L;
+            if (ok && key_mask) ok = key_mask[(size_t)b * L + key] != 0;
+            bias_lds[tid] = ok ? 0.f : -INFINITY;
+        }
+    };
+
+    const int n_tiles = (L + KT - 1) / KT;
+    load_tile(0);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int kt0 = t * KT;
+        __syncthreads();  // every wave is done reading the previous tile
+        write_tile(kt0);
+        __syncthreads();
+        if (t + 1 < n_tiles) load_tile(kt0 + KT);
+
+        // ---- S^T[key][q] for two 32-key blocks ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *(const bf16x8*)(k_lds + (kb * 32 + r) * K_STRIDE + (2 * ds + hg) * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+            }
+        }
+        const bool need_bias = (key_mask != nullptr) || (kt0 + KT > L);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+                if (need_bias) bias = *(const f32x4*)(bias_lds + kb * 32 + 8 * c + 4 * hg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = s[kb][4 * c + e] * scale_log2e + bias[e];
+                    s[kb][4 * c + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(s[kb][e] - m_use);
+                psum += pv;
+                pb[kb][e >> 3][e & 7] = (__bf16)pv;
+            }
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+
+        // ---- O^T[dd][q] += V^T[dd][key] P^T[key][q] ----
+        const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+        const unsigned char* vbase = v_lds + (4 * hg + q4) * V_STRIDE + (16 * g1 + 4 * p4) * 2;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const unsigned char* vk = vbase + (kb * 32 + 16 * ss) * V_STRIDE;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const s16x4 lo = tr_read(vk + db * 64);
+                    const s16x4 hi = tr_read(vk + db * 64 + 8 * V_STRIDE);
+                    u16x8 vv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vv[e] = (unsigned short)lo[e];
+                        vv[e + 4] = (unsigned short)hi[e];
+                    }
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pb[kb][ss], o[db],
+                                                                    0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (q < L) {
+        bf16_t* op = out + ((size_t)b * L + q) * d + (size_t)h * HD + 4 * hg;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u32x2 w;
+                w[0] = pack_bf16x2(o[db][4 * c] * inv, o[db][4 * c + 1] * inv);
+                w[1] = pack_bf16x2(o[db][4 * c + 2] * inv, o[db][4 * c + 3] * inv);
+                *(u32x2*)(op + db * 32 + 8 * c) = w;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, void* out, int32_t n_seq,
+                                     int32_t seq_len, int32_t n_heads, void* stream) {
+    LLADA_CHECK_ARG(qkv && out, "attn: null operand");
+    LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_heads > 0, "attn: bad shape");
+    LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
+    const int d = n_heads * HD;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+    dim3 grid((seq_len + QB - 1) / QB, n_heads, n_seq);
+    hipLaunchKernelGGL(attn_bidir_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, key_mask,
+                       (bf16_t*)out, seq_len, d, scale_log2e);
+    LLADA_CHECK_LAUNCH("attn_bidir_kernel");
+    return LLADA_OK;
+}

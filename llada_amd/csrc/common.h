@@ -1,0 +1,73 @@
+// Shared device/host helpers for the gfx950 kernels of libllada_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/llada_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bit pattern
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// Round-to-nearest-even, NaN stays NaN (the compiler emits v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- host side error plumbing -------------------------------------------------------------
+void llada_set_error(const char* fmt, ...);
+
+#define LLADA_CHECK_ARG(cond, ...)           \
+    do {                                     \
+        if (!(cond)) {                       \
+            llada_set_error(__VA_ARGS__);    \
+            return LLADA_ERR_INVALID;        \
+        }                                    \
+    } while (0)
+
+#define LLADA_CHECK_SUPPORTED(cond, ...)     \
+    do {                                     \
+        if (!(cond)) {                       \
+            llada_set_error(__VA_ARGS__);    \
+            return LLADA_ERR_UNSUPPORTED;    \
+        }                                    \
+    } while (0)
+
+#define LLADA_CHECK_LAUNCH(what)                                                    \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            llada_set_error("%s: %s", what, hipGetErrorString(e_));                 \
+            return LLADA_ERR_HIP;                                                   \
+        }                                                                           \
+    } while (0)

@@ -1,0 +1,107 @@
+// The non-causal LLaDA-8B forward as one C call: replaces `model(x, attention_mask=...).logits`
+// (generate.py:88,92; get_log_likelihood.py:38).  Host-side orchestration only: it enqueues the
+// kernels of gemm.hip / attention.hip / elementwise.hip on the caller's stream and returns; all
+// scratch lives in the caller's workspace.  The LM head runs only on the rows the caller asks
+// for: the sampler needs logits just for the current block (everything else is overwritten by
+// generate.py:125-128), the likelihood just for the answer positions.
+#include "common.h"
+
+namespace {
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t x, h, qkv, att, act, gu, hf, total;
+};
+
+Layout make_layout(const llada_config& c, int64_t M, int64_t R) {
+    Layout o{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align256(bytes);
+        return at;
+    };
+    const size_t d = c.d_model, F = c.mlp_hidden;
+    o.x = take(M * d * 2);
+    o.h = take(M * d * 2);
+    o.qkv = take(M * 3 * d * 2);
+    o.att = take(M * d * 2);
+    o.act = take(M * F * 2);
+    o.gu = take(M * 2 * F * 2);
+    o.hf = take(R * d * 2);
+    o.total = off;
+    return o;
+}
+
+}  // namespace
+
+extern "C" size_t llada_forward_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len,
+                                                int32_t n_logit_rows) {
+    if (!cfg || n_seq <= 0 || seq_len <= 0 || n_logit_rows <= 0) return 0;
+    return make_layout(*cfg, (int64_t)n_seq * seq_len, n_logit_rows).total;
+}
+
+#define TRY(call)                    \
+    do {                             \
+        const int rc_ = (call);      \
+        if (rc_ != LLADA_OK) return rc_; \
+    } while (0)
+
+extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
+                             const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
+                             int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    LLADA_CHECK_ARG(cfg && w && ids && rope_cos && rope_sin && logits_out && workspace, "forward: null argument");
+    LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_logit_rows > 0, "forward: bad shape");
+    const llada_config& c = *cfg;
+    LLADA_CHECK_SUPPORTED(c.n_heads > 0 && c.d_model == c.n_heads * 128, "forward: head_dim must be 128");
+    LLADA_CHECK_SUPPORTED(c.d_model % 256 == 0 && c.mlp_hidden % 64 == 0 && c.vocab_size % 8 == 0,
+                          "forward: d_model %% 256, mlp_hidden %% 64, vocab %% 8 must be 0");
+    const int64_t M = (int64_t)n_seq * seq_len;
+    LLADA_CHECK_ARG(logit_rows != nullptr || n_logit_rows == M, "forward: logit_rows is required unless all rows are wanted");
+    const Layout lay = make_layout(c, M, n_logit_rows);
+    if (workspace_bytes < lay.total) {
+        llada_set_error("forward: workspace has %zu bytes, %zu needed", workspace_bytes, lay.total);
+        return LLADA_ERR_WORKSPACE;
+    }
+    unsigned char* ws = (unsigned char*)workspace;
+    void* x = ws + lay.x;
+    void* h = ws + lay.h;
+    void* qkv = ws + lay.qkv;
+    void* att = ws + lay.att;
+    void* act = ws + lay.act;
+    void* gu = ws + lay.gu;
+    void* hf = ws + lay.hf;
+    const int d = c.d_model, F = c.mlp_hidden, V = c.vocab_size;
+
+    TRY(llada_embed_bf16(w->wte, ids, x, M, d, V, stream));
+    for (int l = 0; l < c.n_layers; ++l) {
+        TRY(llada_rmsnorm_bf16(x, w->attn_norm[l], h, M, d, c.rms_eps, nullptr, stream));
+        if (w->packed) {
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, rope_cos,
+                                rope_sin, seq_len, stream));
+        } else {
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+                                nullptr, 0, stream));
+            TRY(llada_rope_bf16(qkv, rope_cos, rope_sin, n_seq, seq_len, c.n_heads, stream));
+        }
+        TRY(llada_attn_bidir_bf16(qkv, key_mask, att, n_seq, seq_len, c.n_heads, stream));
+        TRY(llada_gemm_bf16(att, w->wo[l], x, M, d, d, d, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0, stream));
+        TRY(llada_rmsnorm_bf16(x, w->ff_norm[l], h, M, d, c.rms_eps, nullptr, stream));
+        if (w->packed) {
+            TRY(llada_gemm_bf16(h, w->wgu[l], act, M, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr,
+                                0, stream));
+        } else {
+            TRY(llada_gemm_bf16(h, w->wgu[l], gu, M, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+                                nullptr, 0, stream));
+            TRY(llada_swiglu_bf16(gu, act, M, F, stream));
+        }
+        TRY(llada_gemm_bf16(act, w->wdown[l], x, M, d, F, F, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0,
+                            stream));
+    }
+    TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, n_logit_rows, d, c.rms_eps, logit_rows, stream));
+    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, n_logit_rows, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+                        nullptr, 0, stream));
+    return LLADA_OK;
+}

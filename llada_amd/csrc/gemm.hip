@@ -1,0 +1,398 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] @ W[N,K]^T, float32 accumulation.
+//
+// Replaces the cuBLAS calls behind every nn.Linear of the mask predictor that the reference
+// invokes at generate.py:88,92 and get_log_likelihood.py:38 (q/k/v, attn_out, ff_proj/up_proj,
+// ff_out and the LM head).
+//
+// Tile: (MFR*32) x 256 x 64 per 512-thread workgroup (8 waves as 2(M) x 4(N), one workgroup per
+// CU), v_mfma_f32_16x16x32_bf16, operands staged global -> LDS by 16-byte LDS-DMA
+// (global_load_lds_dwordx4) into two stages.  LDS rows are 128 B (64 k); the 16-byte chunk c of
+// row r is stored at chunk c ^ ((r >> 1) & 7), applied on the global SOURCE address (the DMA
+// writes LDS linearly) and again on the ds_read_b128 address, which makes every 16-lane read
+// group hit 16 distinct 16-byte slots.  The weight fragment is the MFMA A operand, so a lane
+// ends up with 4 consecutive output columns of one row (8-byte stores, and rotary / SwiGLU
+// partners in the same lane thanks to the packed weight layouts).
+#include "common.h"
+
+namespace {
+
+constexpr int BN = 256;
+constexpr int BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int ROW_BYTES = BK * 2;  // 128
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    bf16_t* C;
+    const bf16_t* R;
+    const float* rope_cos;
+    const float* rope_sin;
+    int M, N, K;
+    int lda, ldc, ldr;
+    int tiles_m, tiles_n;
+    int seq_len;
+    int rope_cols;  // columns < rope_cols get the rotary embedding (2 * d_model)
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_uniform) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_uniform, 16, 0, 0);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+// tiles, and walk the tiles in bands of 8 M-tiles so the 32 tiles resident on an XCD share
+// their A rows and W rows through that XCD's L2.  Bijective for any tile count.
+__device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GM = 8;
+    const int band = wg / (GM * tiles_n);
+    const int first_m = band * GM;
+    const int rows = min(GM, tiles_m - first_m);
+    const int in_band = wg - band * GM * tiles_n;
+    tm = first_m + in_band % rows;
+    tn = in_band / rows;
+}
+
+template <int MFR, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = MFR * 32;
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int B_BYTES = BN * ROW_BYTES;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_LOADS = BM / 64;  // 16-byte DMA instructions per wave per stage
+    constexpr int B_LOADS = BN / 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane DMA source addresses (row clamped into the matrix; chunk pre-swizzled) ----
+    const bf16_t* a_src[A_LOADS];
+    const bf16_t* b_src[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int grow = min(m0 + row, p.M - 1);
+        a_src[i] = p.A + (size_t)grow * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int grow = min(n0 + row, p.N - 1);
+        b_src[i] = p.W + (size_t)grow * p.K + chunk * 8;
+    }
+
+    auto stage = [&](int s, int kt) {
+        unsigned char* base = smem + s * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) glds16(a_src[i] + kt * BK, base + (i * 8 + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) glds16(b_src[i] + kt * BK, base + A_BYTES + (i * 8 + wave) * 1024);
+    };
+
+    f32x4 acc[MFR][4];
+#pragma unroll
+    for (int i = 0; i < MFR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = fr >> 1;
+    const int a_row_off = (wm * MFR * 16 + fr) * ROW_BYTES;
+    const int b_row_off = (wn * 64 + fr) * ROW_BYTES;
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // stage kt has landed (vmcnt(0) + barrier); everyone is done with the other stage
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* As = smem + (kt & 1) * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ swz) * 16;
+            bf16x8 af[MFR], wf[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) wf[nf] = *(const bf16x8*)(Bs + b_row_off + nf * 16 * ROW_BYTES + coff);
+#pragma unroll
+            for (int mf = 0; mf < MFR; ++mf) af[mf] = *(const bf16x8*)(As + a_row_off + mf * 16 * ROW_BYTES + coff);
+#pragma unroll
+            for (int mf = 0; mf < MFR; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], af[mf], acc[mf][nf], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m][n .. n+3], m = row(mf) , n = col(nf) ----
+    const int m_base = m0 + wm * MFR * 16 + fr;
+    const int n_base = n0 + wn * 64 + fq * 4;
+    if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
+#pragma unroll
+        for (int mf = 0; mf < MFR; ++mf) {
+            const int m = m_base + mf * 16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = n_base + nf * 16;
+                if (n >= p.N) continue;
+                f32x4 v = acc[mf][nf];
+                if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+                    const u32x2 r = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
+                    v[0] = bf16_to_f32(r[0] & 0xFFFF) + round_bf16(v[0]);
+                    v[1] = bf16_to_f32(r[0] >> 16) + round_bf16(v[1]);
+                    v[2] = bf16_to_f32(r[1] & 0xFFFF) + round_bf16(v[2]);
+                    v[3] = bf16_to_f32(r[1] >> 16) + round_bf16(v[3]);
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0], v[1]);
+                o[1] = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+            }
+        }
+    } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
+        // packed head layout: 16-column blocks 0-15 | 64-79 | 16-31 | 80-95 | ...; this wave holds
+        // blocks (nf, nf+1) = rotary pairs.  Columns >= rope_cols (the V third) are stored as is.
+        const bool rope = n0 < p.rope_cols;  // uniform per tile: rope_cols % 256 == 0
+#pragma unroll
+        for (int mf = 0; mf < MFR; ++mf) {
+            const int m = m_base + mf * 16;
+            if (m >= p.M) continue;
+            const int pos = m % p.seq_len;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 x1 = acc[mf][2 * pr], x2 = acc[mf][2 * pr + 1];
+                f32x4 o1, o2;
+                if (rope) {
+                    const int j = (wn & 1) * 32 + pr * 16 + fq * 4;  // rotary frequency index of reg 0
+                    const f32x4 c = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
+                    const f32x4 s = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = round_bf16(x1[e]), b = round_bf16(x2[e]);
+                        o1[e] = a * c[e] - b * s[e];
+                        o2[e] = b * c[e] + a * s[e];
+                    }
+                } else {
+                    o1 = x1;
+                    o2 = x2;
+                }
+                const int n1 = n_base + (2 * pr) * 16, n2 = n1 + 16;
+                u32x2 w1, w2;
+                w1[0] = pack_bf16x2(o1[0], o1[1]);
+                w1[1] = pack_bf16x2(o1[2], o1[3]);
+                w2[0] = pack_bf16x2(o2[0], o2[1]);
+                w2[1] = pack_bf16x2(o2[2], o2[3]);
+                *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
+                *(u32x2*)(p.C + (size_t)m * p.ldc + n2) = w2;
+            }
+        }
+    } else {  // LLADA_EPI_SWIGLU: blocks (nf even, nf odd) = (gate, up) of the same 16 hidden units
+        const bool cols_in = n0 + wn * 64 < p.N;  // N % 64 == 0: a wave's 64 columns are all in or all out
+#pragma unroll
+        for (int mf = 0; mf < MFR; ++mf) {
+            const int m = m_base + mf * 16;
+            if (m >= p.M || !cols_in) continue;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const f32x4 g = acc[mf][2 * pr], u = acc[mf][2 * pr + 1];
+                const int f = (n0 + wn * 64) / 2 + pr * 16 + fq * 4;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gb = round_bf16(g[e]);
+                    const float act = round_bf16(gb / (1.0f + __expf(-gb)));
+                    o[e] = act * round_bf16(u[e]);
+                }
+                u32x2 w;
+                w[0] = pack_bf16x2(o[0], o[1]);
+                w[1] = pack_bf16x2(o[2], o[3]);
+                *(u32x2*)(p.C + (size_t)m * p.ldc + f) = w;
+            }
+        }
+    }
+}
+
+template <int MFR, int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    constexpr int BM = MFR * 32;
+    constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MFR, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+            return LLADA_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    GemmParams q = p;
+    q.tiles_m = (int)((p.M + BM - 1) / BM);
+    q.tiles_n = (p.N + BN - 1) / BN;
+    const int nt = q.tiles_m * q.tiles_n;
+    hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(nt), dim3(NTHREADS), lds, stream, q);
+    LLADA_CHECK_LAUNCH("gemm_bf16_kernel");
+    return LLADA_OK;
+}
+
+// Pick the M tile (128 / 192 / 256 rows) that wastes the least work: padding rows plus the
+// idle CUs of the last, partially filled round of tiles over the 256 CUs.
+int pick_mfr(int64_t M, int N) {
+    const int cands[3] = {8, 6, 4};
+    int best = 8;
+    double best_cost = 1e30;
+    const int tiles_n = (N + BN - 1) / BN;
+    for (int c : cands) {
+        const int bm = c * 32;
+        const int64_t tiles_m = (M + bm - 1) / bm;
+        const int64_t nt = tiles_m * tiles_n;
+        const int64_t rounds = (nt + 255) / 256;
+        // time ~ rounds * (tile work); smaller tiles pay a little more per flop (operand traffic)
+        const double cost = (double)rounds * bm * (c == 8 ? 1.0 : (c == 6 ? 1.03 : 1.10));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+template <int EPI>
+int dispatch_mfr(const GemmParams& p, int mfr, hipStream_t stream) {
+    switch (mfr) {
+        case 8: return launch<8, EPI>(p, stream);
+        case 6: return launch<6, EPI>(p, stream);
+        default: return launch<4, EPI>(p, stream);
+    }
+}
+
+}  // namespace
+
+// Test hook: force the M tile (0 = automatic).
+static int g_force_mfr = 0;
+extern "C" void llada_gemm_force_tile_rows(int rows) { g_force_mfr = rows / 32; }
+
+// Measurement hook (bench.py): while active, every launch of the GEMM with the chosen epilogue is
+// bracketed by a pair of HIP events on the launch stream, so the kernel's average duration inside
+// the timed region can be read without a profiler.  Not used by the product path.
+namespace {
+struct GemmProfile {
+    int epilogue = -1;
+    int capacity = 0, count = 0;
+    hipEvent_t* start = nullptr;
+    hipEvent_t* stop = nullptr;
+} g_prof;
+}  // namespace
+
+extern "C" int llada_gemm_profile_begin(int epilogue, int max_samples) {
+    if (g_prof.start) return LLADA_ERR_INVALID;
+    g_prof.start = new hipEvent_t[max_samples];
+    g_prof.stop = new hipEvent_t[max_samples];
+    for (int i = 0; i < max_samples; ++i) {
+        if (hipEventCreate(&g_prof.start[i]) != hipSuccess || hipEventCreate(&g_prof.stop[i]) != hipSuccess) {
+            llada_set_error("gemm_profile_begin: hipEventCreate failed");
+            return LLADA_ERR_HIP;
+        }
+    }
+    g_prof.capacity = max_samples;
+    g_prof.count = 0;
+    g_prof.epilogue = epilogue;
+    return LLADA_OK;
+}
+
+// Blocks until the recorded launches have finished; returns their summed duration and count.
+extern "C" int llada_gemm_profile_end(double* total_ms, int* n_samples) {
+    if (!g_prof.start) return LLADA_ERR_INVALID;
+    double tot = 0.0;
+    const int n = g_prof.count < g_prof.capacity ? g_prof.count : g_prof.capacity;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(g_prof.stop[i]);
+        (void)hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]);
+        tot += ms;
+    }
+    for (int i = 0; i < g_prof.capacity; ++i) {
+        (void)hipEventDestroy(g_prof.start[i]);
+        (void)hipEventDestroy(g_prof.stop[i]);
+    }
+    delete[] g_prof.start;
+    delete[] g_prof.stop;
+    g_prof = GemmProfile{};
+    if (total_ms) *total_ms = tot;
+    if (n_samples) *n_samples = n;
+    return LLADA_OK;
+}
+
+static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, int ldr, const float* rope_cos,
+                         const float* rope_sin, int seq_len, int ldc, int N, hipStream_t s);
+
+extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int32_t N, int32_t K, int32_t lda,
+                               int32_t ldc, int32_t epilogue, const void* aux, int32_t ldr, const float* rope_cos,
+                               const float* rope_sin, int32_t seq_len, void* stream) {
+    LLADA_CHECK_ARG(A && W && C, "gemm: null operand");
+    LLADA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    LLADA_CHECK_SUPPORTED(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
+    LLADA_CHECK_SUPPORTED(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
+    LLADA_CHECK_SUPPORTED(M < (1ll << 31), "gemm: M too large");
+    LLADA_CHECK_ARG(lda >= K && (lda % 8) == 0, "gemm: lda=%d must be >= K and a multiple of 8", lda);
+    LLADA_CHECK_ARG((ldc % 4) == 0, "gemm: ldc=%d must be a multiple of 4", ldc);
+    GemmParams p{};
+    p.A = (const bf16_t*)A;
+    p.W = (const bf16_t*)W;
+    p.C = (bf16_t*)C;
+    p.R = (const bf16_t*)aux;
+    p.rope_cos = rope_cos;
+    p.rope_sin = rope_sin;
+    p.M = (int)M;
+    p.N = N;
+    p.K = K;
+    p.lda = lda;
+    p.ldc = ldc;
+    p.ldr = ldr;
+    p.seq_len = seq_len;
+    hipStream_t s = (hipStream_t)stream;
+    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N);
+    LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
+    const bool prof = g_prof.epilogue == epilogue && g_prof.count < g_prof.capacity;
+    if (prof) (void)hipEventRecord(g_prof.start[g_prof.count], s);
+    const int rc = gemm_dispatch(p, epilogue, mfr, aux, ldr, rope_cos, rope_sin, seq_len, ldc, N, s);
+    if (prof) (void)hipEventRecord(g_prof.stop[g_prof.count++], s);
+    return rc;
+}
+
+static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, int ldr, const float* rope_cos,
+                         const float* rope_sin, int seq_len, int ldc, int N, hipStream_t s) {
+    switch (epilogue) {
+        case LLADA_EPI_PLAIN:
+            LLADA_CHECK_ARG(ldc >= N, "gemm: ldc < N");
+            return dispatch_mfr<LLADA_EPI_PLAIN>(p, mfr, s);
+        case LLADA_EPI_RESIDUAL:
+            LLADA_CHECK_ARG(aux != nullptr && ldr >= N && (ldr % 4) == 0 && ldc >= N, "gemm: residual needs aux/ldr");
+            return dispatch_mfr<LLADA_EPI_RESIDUAL>(p, mfr, s);
+        case LLADA_EPI_ROPE_QKV:
+            LLADA_CHECK_ARG(rope_cos && rope_sin && seq_len > 0 && ldc >= N, "gemm: rope epilogue needs tables and seq_len");
+            LLADA_CHECK_SUPPORTED(N % 3 == 0 && (N / 3) % BN == 0, "gemm: rope epilogue needs d_model %% 256 == 0");
+            p.rope_cols = 2 * (N / 3);
+            return dispatch_mfr<LLADA_EPI_ROPE_QKV>(p, mfr, s);
+        case LLADA_EPI_SWIGLU:
+            LLADA_CHECK_SUPPORTED(N % 64 == 0, "gemm: swiglu epilogue needs N %% 64 == 0");
+            LLADA_CHECK_ARG(ldc >= N / 2, "gemm: ldc < N/2");
+            return dispatch_mfr<LLADA_EPI_SWIGLU>(p, mfr, s);
+        default:
+            llada_set_error("gemm: unknown epilogue %d", epilogue);
+            return LLADA_ERR_INVALID;
+    }
+}

@@ -1,0 +1,172 @@
+// Monte-Carlo masked log-likelihood pieces around the forward (get_log_likelihood.py:7-26, 66-75).
+//
+//   ll_mask_kernel   : forward_process -- per row, counts[r] answer positions become the mask token,
+//                      chosen by an injected permutation (parity tests) or by the counts[r] smallest
+//                      Philox keys of the row (uniformly random subset, like masking a randperm prefix).
+//   masked_ce_kernel : one workgroup per answer-position logits row; rows whose noisy token is not the
+//                      mask contribute 0.  Fuses the CFG combine (get_log_likelihood.py:41-42),
+//                      F.cross_entropy(reduction='none') on bf16 logits (:72) and the division by
+//                      p_mask; a second tiny kernel adds the row losses in a fixed order (float64).
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr int RT = 512;
+
+__global__ void __launch_bounds__(256) ll_mask_kernel(const int64_t* __restrict__ seq, int64_t* __restrict__ noisy,
+                                                      int l, int prompt_len, int64_t mask_id,
+                                                      const int32_t* __restrict__ counts,
+                                                      const int32_t* __restrict__ perms, uint64_t seed,
+                                                      uint32_t iteration, uint32_t row_offset) {
+    extern __shared__ uint32_t keys[];  // [target_len] when perms == nullptr
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int T = l - prompt_len;
+    const int count = counts[r];
+    for (int i = tid; i < prompt_len; i += 256) noisy[(size_t)r * l + i] = seq[(size_t)r * l + i];
+    if (perms) {
+        for (int j = tid; j < T; j += 256) {
+            const size_t p = (size_t)r * l + prompt_len + j;
+            noisy[p] = perms[(size_t)r * T + j] < count ? mask_id : seq[p];
+        }
+        return;
+    }
+    uint32_t k0, k1;
+    philox_key(seed, LLADA_STREAM_LL, k0, k1);
+    for (int j = tid; j < T; j += 256)
+        keys[j] = philox4x32_10((uint32_t)j, 0u, row_offset + (uint32_t)r, iteration, k0, k1).v[0];
+    __syncthreads();
+    for (int j = tid; j < T; j += 256) {
+        const uint32_t kj = keys[j];
+        int rank = 0;
+        for (int i = 0; i < T; ++i) {
+            const uint32_t ki = keys[i];
+            rank += (ki < kj) || (ki == kj && i < j);
+        }
+        const size_t p = (size_t)r * l + prompt_len + j;
+        noisy[p] = rank < count ? mask_id : seq[p];
+    }
+}
+
+__device__ __forceinline__ float cfg_combine(float c, float u, float cfg1) {
+    float d = round_bf16(c - u);
+    d = round_bf16(d * cfg1);
+    return round_bf16(u + d);
+}
+
+__global__ void __launch_bounds__(RT) masked_ce_kernel(const bf16_t* __restrict__ logits,
+                                                       const bf16_t* __restrict__ uncond, float cfg1,
+                                                       const int32_t* __restrict__ row_pos, int V,
+                                                       const int64_t* __restrict__ noisy,
+                                                       const int64_t* __restrict__ seq, int l, int64_t mask_id,
+                                                       const float* __restrict__ p_mask_rows, int round_ce,
+                                                       float* __restrict__ row_loss) {
+    __shared__ float red[RT / 64];
+    __shared__ float bc[2];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = row_pos ? row_pos[r] : r;
+    if (noisy[pos] != mask_id) {
+        if (tid == 0) row_loss[r] = 0.f;
+        return;
+    }
+    const bf16_t* lc = logits + (size_t)r * V;
+    const bf16_t* lu = uncond ? uncond + (size_t)r * V : nullptr;
+    const int chunks = V / 8;
+    auto load = [&](int c, float (&v)[8]) {
+        const u16x8 a = *(const u16x8*)(lc + (size_t)c * 8);
+        if (lu) {
+            const u16x8 u = *(const u16x8*)(lu + (size_t)c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = cfg_combine(bf16_to_f32(a[e]), bf16_to_f32(u[e]), cfg1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32(a[e]);
+        }
+    };
+    float mx = -INFINITY;
+    for (int c = tid; c < chunks; c += RT) {
+        float v[8];
+        load(c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
+    }
+    mx = wave_reduce_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        float m = red[0];
+        for (int w = 1; w < RT / 64; ++w) m = fmaxf(m, red[w]);
+        bc[0] = m;
+    }
+    __syncthreads();
+    const float m = bc[0];
+    float s = 0.f;
+    for (int c = tid; c < chunks; c += RT) {
+        float v[8];
+        load(c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += expf(v[e] - m);
+    }
+    s = wave_reduce_sum(s);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < RT / 64; ++w) tot += red[w];
+        const int64_t tgt = seq[pos];
+        float lt = bf16_to_f32(lc[tgt]);
+        if (lu) lt = cfg_combine(lt, bf16_to_f32(lu[tgt]), cfg1);
+        float logp = (lt - m) - logf(tot);
+        if (round_ce) logp = round_bf16(logp);
+        row_loss[r] = -logp / p_mask_rows[pos / l];
+    }
+}
+
+__global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ row_loss, int n,
+                                                       double* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)row_loss[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+}  // namespace
+
+extern "C" int llada_ll_mask(const int64_t* seq, int64_t* noisy, int32_t b, int32_t l, int32_t prompt_len,
+                             int64_t mask_id, const int32_t* counts, const int32_t* perms, uint64_t seed,
+                             uint32_t iteration, uint32_t row_offset, void* stream) {
+    LLADA_CHECK_ARG(seq && noisy && counts && b > 0 && l > 0, "ll_mask: bad argument");
+    LLADA_CHECK_ARG(prompt_len >= 0 && prompt_len < l, "ll_mask: prompt_len must leave at least one answer token");
+    const int T = l - prompt_len;
+    LLADA_CHECK_SUPPORTED(T <= 15360, "ll_mask: answer too long (%d)", T);
+    hipLaunchKernelGGL(ll_mask_kernel, dim3(b), dim3(256), perms ? 0 : (size_t)T * sizeof(uint32_t),
+                       (hipStream_t)stream, seq, noisy, l, prompt_len, mask_id, counts, perms, seed, iteration,
+                       row_offset);
+    LLADA_CHECK_LAUNCH("ll_mask_kernel");
+    return LLADA_OK;
+}
+
+extern "C" int llada_masked_ce(const void* logits, const void* uncond_logits, double cfg_scale, const int32_t* row_pos,
+                               int32_t n_rows, int32_t vocab, const int64_t* noisy, const int64_t* seq, int32_t b,
+                               int32_t l, int64_t mask_id, const float* p_mask_rows, int32_t round_ce_bf16,
+                               float* row_loss, double* loss_sum, void* stream) {
+    LLADA_CHECK_ARG(logits && noisy && seq && p_mask_rows && row_loss && loss_sum, "masked_ce: null tensor");
+    LLADA_CHECK_ARG(n_rows > 0 && vocab > 0 && b > 0 && l > 0, "masked_ce: bad shape");
+    LLADA_CHECK_SUPPORTED(vocab % 8 == 0, "masked_ce: vocab=%d must be a multiple of 8", vocab);
+    LLADA_CHECK_ARG(row_pos != nullptr || n_rows == b * l, "masked_ce: row_pos is required unless n_rows == b*l");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(masked_ce_kernel, dim3(n_rows), dim3(RT), 0, s, (const bf16_t*)logits,
+                       (const bf16_t*)uncond_logits, (float)(cfg_scale + 1.0), row_pos, vocab, noisy, seq, l, mask_id,
+                       p_mask_rows, round_ce_bf16, row_loss);
+    LLADA_CHECK_LAUNCH("masked_ce_kernel");
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, s, row_loss, n_rows, loss_sum);
+    LLADA_CHECK_LAUNCH("sum_rows_kernel");
+    return LLADA_OK;
+}

@@ -1,0 +1,392 @@
+// Remasking epilogue of one denoising step (generate.py:81-134 after the forward), HBM-bound.
+//
+//   remask_rows_kernel : one workgroup per logits row that can matter (a mask token inside the
+//                        current block).  Fuses the CFG combine (generate.py:89-90), the EOS/EoT
+//                        controls (:94-95, :100-101), add_gumbel_noise in float64 (:8-19),
+//                        argmax (:98), the vocab softmax and the confidence rule (:103-123), the
+//                        block clamp and the two where() (:125-128).
+//   topk_transfer_kernel: per batch row, torch.topk + the masked scatter (:130-134) with k read
+//                        from the device schedule, so the step loop never synchronises the host.
+//   num_transfer_kernel : get_num_transfer_tokens (:22-40) on the block slice (:75-79).
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr int RT = 512;  // threads per logits row
+
+struct ArgD {
+    double v;
+    int i;
+};
+struct ArgF {
+    float v;
+    int i;
+};
+
+// torch.argmax semantics: first index among equal maxima.
+template <class A>
+__device__ __forceinline__ A arg_better(A a, A b) {
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+template <class A>
+__device__ __forceinline__ A wave_argmax(A a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        A b;
+        b.v = __shfl_xor(a.v, o);
+        b.i = __shfl_xor(a.i, o);
+        a = arg_better(a, b);
+    }
+    return a;
+}
+
+struct RowCtx {
+    const bf16_t* lc;  // conditional logits row
+    const bf16_t* lu;  // unconditional logits row or nullptr
+    float cfg1;        // cfg_scale + 1
+    int eos_for_logits;   // vocab id forced to -inf before sampling, or -1
+    int sm_excl0, sm_excl1;  // vocab ids excluded from the softmax (set to -inf after x0 is taken), or -1
+};
+
+// generate.py:89-90 on one element, each op rounding to bf16 as torch does on bf16 tensors
+__device__ __forceinline__ float cfg_combine(float c, float u, float cfg1) {
+    float d = round_bf16(c - u);
+    d = round_bf16(d * cfg1);
+    return round_bf16(u + d);
+}
+
+__device__ __forceinline__ void load_chunk(const RowCtx& rc, int chunk, float (&l)[8]) {
+    const u16x8 c = *(const u16x8*)(rc.lc + (size_t)chunk * 8);
+    if (rc.lu) {
+        const u16x8 u = *(const u16x8*)(rc.lu + (size_t)chunk * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = cfg_combine(bf16_to_f32(c[e]), bf16_to_f32(u[e]), rc.cfg1);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = bf16_to_f32(c[e]);
+    }
+    const int v0 = chunk * 8;
+    if (rc.eos_for_logits >= v0 && rc.eos_for_logits < v0 + 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (v0 + e == rc.eos_for_logits) l[e] = -INFINITY;
+    }
+}
+
+__device__ __forceinline__ float softmax_view(const RowCtx& rc, int v, float l) {
+    return (v == rc.sm_excl0 || v == rc.sm_excl1) ? -INFINITY : l;
+}
+
+__global__ void remask_default_kernel(const int64_t* __restrict__ x, int64_t* __restrict__ x0,
+                                      float* __restrict__ conf, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x0[i] = x[i];
+        conf[i] = -INFINITY;
+    }
+}
+
+template <bool GUMBEL>
+__global__ void __launch_bounds__(RT) remask_rows_kernel(const llada_remask_args a) {
+    __shared__ float red_f[RT / 64];
+    __shared__ int red_i[RT / 64];
+    __shared__ double red_d[RT / 64];
+    __shared__ float bc_f[2];
+    __shared__ int bc_i;
+
+    const int r = blockIdx.x;
+    const int pos = a.row_pos ? a.row_pos[r] : r;
+    const int b = pos / a.L, col = pos - b * a.L;
+    if (a.x[pos] != a.mask_id || col >= a.block_end) return;  // defaults already written (uniform exit)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.vocab, chunks = V / 8;
+    RowCtx rc;
+    rc.lc = (const bf16_t*)a.logits + (size_t)r * V;
+    rc.lu = a.uncond_logits ? (const bf16_t*)a.uncond_logits + (size_t)r * V : nullptr;
+    rc.cfg1 = (float)(a.cfg_scale + 1.0);
+    rc.eos_for_logits = (a.flags & LLADA_FLAG_LOGITS_EOS_INF) ? a.eos_id : -1;
+    rc.sm_excl0 = rc.sm_excl1 = -1;
+    if (a.flags & LLADA_FLAG_CONF_EOS_EOT_INF) {
+        // generate.py:101 `logits_with_noise[..EOS] = logits[..EoT] = -inf`: at temperature 0 both
+        // names are one tensor, so the softmax loses EOS and EoT; otherwise only EoT.
+        rc.sm_excl0 = a.eot_id;
+        if (!GUMBEL) rc.sm_excl1 = a.eos_id;
+    }
+    const bool need_softmax = a.remasking != LLADA_REMASK_RANDOM;
+
+    // ---- pass 1: argmax (float64 Gumbel-max when sampling) and the softmax maximum ----
+    float smax = -INFINITY;
+    ArgF bf = {-INFINITY, 0x7fffffff};
+    ArgD bd = {-1.0, 0x7fffffff};
+    uint32_t k0 = 0, k1 = 0;
+    if (GUMBEL) philox_key(a.seed, LLADA_STREAM_GUMBEL, k0, k1);
+    const double temp = (double)a.temperature;
+    for (int c = tid; c < chunks; c += RT) {
+        float l[8];
+        load_chunk(rc, c, l);
+        double u[8];
+        if (GUMBEL) {
+            if (a.noise) {
+                const double* np = a.noise + (size_t)r * V + (size_t)c * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = np[e];
+            } else {
+#pragma unroll
+                for (int h2 = 0; h2 < 4; ++h2) {
+                    const Philox4 ph = philox4x32_10((uint32_t)(c * 4 + h2), (uint32_t)col, a.row_offset + (uint32_t)b,
+                                                     a.step, k0, k1);
+                    u[2 * h2] = u53(ph.v[0], ph.v[1]);
+                    u[2 * h2 + 1] = u53(ph.v[2], ph.v[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int v = c * 8 + e;
+            if (GUMBEL) {
+                // generate.py:16-19: exp(logits) / (-log u) ** T, all float64
+                const double g = pow(-log(u[e]), temp);
+                const double sc = exp((double)l[e]) / g;
+                if (sc > bd.v || (sc == bd.v && v < bd.i)) {
+                    bd.v = sc;
+                    bd.i = v;
+                }
+            } else {
+                if (l[e] > bf.v || (l[e] == bf.v && v < bf.i)) {
+                    bf.v = l[e];
+                    bf.i = v;
+                }
+            }
+            smax = fmaxf(smax, softmax_view(rc, v, l[e]));
+        }
+    }
+    int x0;
+    if (GUMBEL) {
+        bd = wave_argmax(bd);
+        if (lane == 0) {
+            red_d[wave] = bd.v;
+            red_i[wave] = bd.i;
+        }
+    } else {
+        bf = wave_argmax(bf);
+        if (lane == 0) {
+            red_f[wave] = bf.v;
+            red_i[wave] = bf.i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int bi = red_i[0];
+        if (GUMBEL) {
+            double bv = red_d[0];
+            for (int w = 1; w < RT / 64; ++w)
+                if (red_d[w] > bv || (red_d[w] == bv && red_i[w] < bi)) {
+                    bv = red_d[w];
+                    bi = red_i[w];
+                }
+        } else {
+            float bv = red_f[0];
+            for (int w = 1; w < RT / 64; ++w)
+                if (red_f[w] > bv || (red_f[w] == bv && red_i[w] < bi)) {
+                    bv = red_f[w];
+                    bi = red_i[w];
+                }
+        }
+        bc_i = bi;
+    }
+    __syncthreads();
+    x0 = bc_i;
+    smax = wave_reduce_max(smax);
+    if (lane == 0) red_f[wave] = smax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = red_f[0];
+        for (int w = 1; w < RT / 64; ++w) m = fmaxf(m, red_f[w]);
+        bc_f[0] = m;
+    }
+    __syncthreads();
+    const float m = bc_f[0];
+
+    float conf;
+    if (!need_softmax) {
+        if (a.rand_scores) {
+            conf = a.rand_scores[pos];
+        } else {
+            uint32_t r0, r1;
+            philox_key(a.seed, LLADA_STREAM_REMASK, r0, r1);
+            const Philox4 ph = philox4x32_10((uint32_t)col, 0u, a.row_offset + (uint32_t)b, a.step, r0, r1);
+            conf = (float)(ph.v[0] >> 8) * (1.0f / 16777216.0f);
+        }
+    } else {
+        // ---- pass 2: sum of exp(l - max) ----
+        float ssum = 0.f;
+        for (int c = tid; c < chunks; c += RT) {
+            float l[8];
+            load_chunk(rc, c, l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ssum += expf(softmax_view(rc, c * 8 + e, l[e]) - m);
+        }
+        ssum = wave_reduce_sum(ssum);
+        __syncthreads();
+        if (lane == 0) red_f[wave] = ssum;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < RT / 64; ++w) s += red_f[w];
+            bc_f[1] = s;
+        }
+        __syncthreads();
+        const float s = bc_f[1];
+        if (a.remasking == LLADA_REMASK_LOW_CONFIDENCE || a.remasking == LLADA_REMASK_HIGH_CONFIDENCE) {
+            // p[x0], rounded to bf16 like F.softmax on a bf16 tensor
+            float lx;
+            {
+                float c = bf16_to_f32(rc.lc[x0]);
+                if (rc.lu) c = cfg_combine(c, bf16_to_f32(rc.lu[x0]), rc.cfg1);
+                if (x0 == rc.eos_for_logits) c = -INFINITY;
+                lx = softmax_view(rc, x0, c);
+            }
+            const float p = round_bf16(expf(lx - m) / s);
+            conf = (a.remasking == LLADA_REMASK_LOW_CONFIDENCE) ? p : round_bf16(1.0f - p);
+        } else {
+            // ---- pass 3: sum of bf16(log_p * p), both factors rounded to bf16 first ----
+            const float lse = logf(s);
+            float esum = 0.f;
+            for (int c = tid; c < chunks; c += RT) {
+                float l[8];
+                load_chunk(rc, c, l);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = softmax_view(rc, c * 8 + e, l[e]) - m;
+                    const float p = round_bf16(expf(z) / s);
+                    const float lp = round_bf16(z - lse);
+                    esum += round_bf16(lp * p);
+                }
+            }
+            esum = wave_reduce_sum(esum);
+            __syncthreads();
+            if (lane == 0) red_f[wave] = esum;
+            __syncthreads();
+            float tot = 0.f;
+            for (int w = 0; w < RT / 64; ++w) tot += red_f[w];
+            tot = round_bf16(tot);
+            conf = (a.remasking == LLADA_REMASK_LOW_ENTROPY) ? -tot : tot;
+        }
+    }
+    if (tid == 0) {
+        a.x0[pos] = (int64_t)x0;
+        a.confidence[pos] = conf;
+    }
+}
+
+// Order-preserving key of a confidence: NaN ranks highest (torch.topk), -0 == +0.
+__device__ __forceinline__ uint32_t conf_key(float f) {
+    if (f != f) return 0xFFFFFFFFu;
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(256) topk_transfer_kernel(int64_t* __restrict__ x, const int64_t* __restrict__ x0,
+                                                            const float* __restrict__ conf, int L,
+                                                            const int32_t* __restrict__ sched, int sched_stride,
+                                                            int step) {
+    extern __shared__ uint32_t keys[];  // [L]
+    __shared__ int red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int k = sched[(size_t)b * sched_stride + step];
+    if (k <= 0) return;
+    if (k > L) k = L;
+    const uint32_t KEY_NEG_INF = conf_key(-INFINITY);
+    int nc = 0;
+    for (int i = tid; i < L; i += 256) {
+        const uint32_t key = conf_key(conf[(size_t)b * L + i]);
+        keys[i] = key;
+        nc += key > KEY_NEG_INF;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nc += __shfl_xor(nc, o);
+    if ((tid & 63) == 0) red[tid >> 6] = nc;
+    __syncthreads();
+    nc = red[0] + red[1] + red[2] + red[3];
+    const bool only_candidates = k <= nc;  // then no -inf entry can be among the k largest
+    for (int i = tid; i < L; i += 256) {
+        const uint32_t ki = keys[i];
+        if (only_candidates && ki <= KEY_NEG_INF) continue;
+        int rank = 0;
+        for (int j = 0; j < L; ++j) {
+            const uint32_t kj = keys[j];
+            rank += (kj > ki) || (kj == ki && j < i);
+        }
+        if (rank < k) x[(size_t)b * L + i] = x0[(size_t)b * L + i];
+    }
+}
+
+__global__ void __launch_bounds__(256) num_transfer_kernel(const int64_t* __restrict__ x, int L, int block_start,
+                                                           int block_end, int64_t mask_id, int steps,
+                                                           int32_t* __restrict__ sched) {
+    __shared__ int red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = 0;
+    for (int i = block_start + tid; i < block_end; i += 256) n += x[(size_t)b * L + i] == mask_id;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((tid & 63) == 0) red[tid >> 6] = n;
+    __syncthreads();
+    n = red[0] + red[1] + red[2] + red[3];
+    const int base = n / steps, rem = n % steps;
+    for (int s = tid; s < steps; s += 256) sched[(size_t)b * steps + s] = base + (s < rem ? 1 : 0);
+}
+
+}  // namespace
+
+extern "C" int llada_num_transfer_tokens(const int64_t* x, int32_t B, int32_t L, int32_t block_start,
+                                         int32_t block_end, int64_t mask_id, int32_t steps, int32_t* sched,
+                                         void* stream) {
+    LLADA_CHECK_ARG(x && sched && B > 0 && L > 0 && steps > 0, "num_transfer_tokens: bad argument");
+    LLADA_CHECK_ARG(0 <= block_start && block_start <= block_end && block_end <= L, "num_transfer_tokens: bad block");
+    hipLaunchKernelGGL(num_transfer_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, L, block_start, block_end,
+                       mask_id, steps, sched);
+    LLADA_CHECK_LAUNCH("num_transfer_kernel");
+    return LLADA_OK;
+}
+
+extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) {
+    LLADA_CHECK_ARG(args != nullptr, "remask_scores: null args");
+    const llada_remask_args& a = *args;
+    LLADA_CHECK_ARG(a.logits && a.x && a.x0 && a.confidence, "remask_scores: null tensor");
+    LLADA_CHECK_ARG(a.n_rows > 0 && a.B > 0 && a.L > 0 && a.vocab > 0, "remask_scores: bad shape");
+    LLADA_CHECK_SUPPORTED(a.vocab % 8 == 0, "remask_scores: vocab=%d must be a multiple of 8", a.vocab);
+    LLADA_CHECK_ARG(a.row_pos != nullptr || a.n_rows == a.B * a.L, "remask_scores: row_pos is required unless n_rows == B*L");
+    if (a.remasking < LLADA_REMASK_LOW_CONFIDENCE || a.remasking > LLADA_REMASK_RANDOM) {
+        llada_set_error("remask_scores: unknown remasking rule %d", a.remasking);
+        return LLADA_ERR_UNSUPPORTED;  // NotImplementedError(remasking), generate.py:122-123
+    }
+    if (a.flags & (LLADA_FLAG_LOGITS_EOS_INF | LLADA_FLAG_CONF_EOS_EOT_INF))
+        LLADA_CHECK_ARG(a.eos_id >= 0 && a.eos_id < a.vocab && a.eot_id >= 0 && a.eot_id < a.vocab,
+                        "remask_scores: eos/eot id outside the vocabulary");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)a.B * a.L;
+    const int g = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(remask_default_kernel, dim3(g), dim3(256), 0, s, a.x, a.x0, a.confidence, n);
+    LLADA_CHECK_LAUNCH("remask_default_kernel");
+    if (a.temperature != 0.0f)
+        hipLaunchKernelGGL(remask_rows_kernel<true>, dim3(a.n_rows), dim3(RT), 0, s, a);
+    else
+        hipLaunchKernelGGL(remask_rows_kernel<false>, dim3(a.n_rows), dim3(RT), 0, s, a);
+    LLADA_CHECK_LAUNCH("remask_rows_kernel");
+    return LLADA_OK;
+}
+
+extern "C" int llada_topk_transfer(int64_t* x, const int64_t* x0, const float* confidence, int32_t B, int32_t L,
+                                   const int32_t* sched, int32_t sched_stride, int32_t step, void* stream) {
+    LLADA_CHECK_ARG(x && x0 && confidence && sched && B > 0 && L > 0, "topk_transfer: bad argument");
+    LLADA_CHECK_ARG(step >= 0 && step < sched_stride, "topk_transfer: step outside the schedule");
+    LLADA_CHECK_SUPPORTED(L <= 15360, "topk_transfer: L=%d too long", L);
+    hipLaunchKernelGGL(topk_transfer_kernel, dim3(B), dim3(256), (size_t)L * sizeof(uint32_t), (hipStream_t)stream, x,
+                       x0, confidence, L, sched, sched_stride, step);
+    LLADA_CHECK_LAUNCH("topk_transfer_kernel");
+    return LLADA_OK;
+}

@@ -1,0 +1,95 @@
+"""The mask predictor object: the model protocol the reference samplers use
+(``model.device`` at generate.py:60,64; ``model(x, attention_mask=...).logits`` at generate.py:88,92 and
+get_log_likelihood.py:38) on top of the HIP forward, plus the row-restricted fast path that
+``llada_amd.generate`` / ``llada_amd.get_log_likelihood`` use (LM head only on the rows that
+can influence the result).  PyTorch only owns the memory and the stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .weights import LLaDAConfig, LLaDAWeights
+
+
+class ModelOutput:
+    """Stand-in for the HF output object: only ``.logits`` is read by the reference."""
+
+    def __init__(self, logits):
+        self.logits = logits
+
+
+class LLaDAModel:
+    def __init__(self, weights: LLaDAWeights):
+        self.lib = _lib.load()
+        self.weights = weights
+        self.cfg: LLaDAConfig = weights.cfg
+        self.device = weights.device
+        c = self.cfg
+        self._c_cfg = _lib.Config(c.d_model, c.n_layers, c.n_heads, c.mlp_hidden, c.vocab_size, c.rms_eps)
+
+        def arr(ts):
+            return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+        w = weights
+        self._arrays = [arr(w.attn_norm), arr(w.wqkv), arr(w.wo), arr(w.ff_norm), arr(w.wgu), arr(w.wdown)]
+        self._c_w = _lib.Weights(1 if w.packed else 0, w.wte.data_ptr(), w.ln_f.data_ptr(), w.lm_head.data_ptr(),
+                                 *[C.cast(a, C.POINTER(C.c_void_p)) for a in self._arrays])
+        self._ws = None
+        self._rope = {}
+
+    # -- HF-like surface the reference's callers touch -------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def rope_tables(self, L):
+        if L not in self._rope:
+            c = self.cfg
+            inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32) / c.head_dim))
+            ang = torch.arange(L, dtype=torch.float32)[:, None] * inv[None, :]
+            self._rope[L] = (torch.cos(ang).to(self.device).contiguous(), torch.sin(ang).to(self.device).contiguous())
+        return self._rope[L]
+
+    def _workspace(self, n_seq, L, n_rows):
+        need = self.lib.llada_forward_workspace_bytes(C.byref(self._c_cfg), n_seq, L, n_rows)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward_rows(self, input_ids, attention_mask=None, logit_rows=None, out=None):
+        """Forward on ids [n_seq, L]; returns bf16 logits [n_rows, V] for the flat token indices in
+        ``logit_rows`` (int32 tensor) or for every token when it is None."""
+        assert input_ids.dim() == 2 and input_ids.dtype == torch.long
+        ids = input_ids.to(self.device).contiguous()
+        n_seq, L = ids.shape
+        n_rows = n_seq * L if logit_rows is None else int(logit_rows.numel())
+        if logit_rows is not None:
+            assert logit_rows.dtype == torch.int32 and logit_rows.is_contiguous() and logit_rows.device == ids.device
+        km = None
+        if attention_mask is not None:
+            km = (attention_mask.to(self.device) != 0).to(torch.uint8).contiguous()
+            assert km.shape == ids.shape
+        cos, sin = self.rope_tables(L)
+        if out is None:
+            out = torch.empty(n_rows, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
+        ws = self._workspace(n_seq, L, n_rows)
+        rc = self.lib.llada_forward(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
+                                    cos.data_ptr(), sin.data_ptr(), n_seq, L, _lib.ptr(logit_rows), n_rows,
+                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc)
+        return out
+
+    def __call__(self, input_ids, attention_mask=None):
+        n_seq, L = input_ids.shape
+        logits = self.forward_rows(input_ids, attention_mask, None)
+        return ModelOutput(logits.view(n_seq, L, self.cfg.vocab_size))
+
+    forward = __call__

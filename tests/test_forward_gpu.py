@@ -1,0 +1,156 @@
+"""Parity of the HIP forward and of the end-to-end drop-ins on a small LLaDA-shaped model,
+against the oracle (which is pinned to the stand-in vectors, see tests/test_oracle_forward.py)."""
+import numpy as np
+import pytest
+
+from oracle import likelihood as oll
+from oracle import sampler as osamp
+from oracle.model import LLaDAConfig as OCfg
+from oracle.model import OracleModel, forward, init_weights
+from tests.golden_util import MASK_ID, load
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def build(ocfg, W, packed=True):
+    from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights
+    cfg = LLaDAConfig(d_model=ocfg.d_model, n_layers=ocfg.n_layers, n_heads=ocfg.n_heads, mlp_hidden=ocfg.mlp_hidden,
+                      vocab_size=ocfg.vocab_size, rope_theta=ocfg.rope_theta, rms_eps=ocfg.rms_eps)
+    return LLaDAModel(LLaDAWeights.from_numpy(cfg, W, "cuda", packed=packed))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    z, _ = load("forward_standin.npz")
+    d, nl, nh, ff, V = (int(v) for v in z["cfg"])
+    ocfg = OCfg(d_model=d, n_layers=nl, n_heads=nh, mlp_hidden=ff, vocab_size=V)
+    W = init_weights(ocfg, seed=int(z["weight_seed"][0]), std=float(z["weight_std"][0]),
+                     head_scale=float(z["head_scale"][0]))
+    return z, ocfg, W
+
+
+def max_rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_forward_logits(lib, tiny, packed):
+    z, ocfg, W = tiny
+    model = build(ocfg, W, packed)
+    ids = torch.from_numpy(z["ids"]).cuda()
+    for mask, key in ((None, "logits_nomask"), (z["key_mask"], "logits_padmask")):
+        am = None if mask is None else torch.from_numpy(mask).cuda()
+        lg = model(ids, attention_mask=am).logits
+        assert lg.dtype == torch.bfloat16 and tuple(lg.shape) == (2, 24, ocfg.vocab_size)
+        got = lg.float().cpu().numpy()
+        ref = forward(W, ocfg, z["ids"], mask, emulate_bf16=True)
+        assert max_rel(got, ref) <= 2e-2, max_rel(got, ref)        # contract: bf16 tolerance, max rel 2e-2
+        assert max_rel(got, z[key]) <= 2e-2, max_rel(got, z[key])  # and against the float32 stand-in itself
+
+
+def test_forward_row_subset_is_exact(lib, tiny):
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    ids = torch.from_numpy(z["ids"]).cuda()
+    full = model(ids).logits.reshape(-1, ocfg.vocab_size)
+    rows = torch.tensor([47, 0, 5, 23, 24, 31], dtype=torch.int32, device="cuda")
+    sub = model.forward_rows(ids, None, rows)
+    assert torch.equal(sub, full[rows.long()])
+
+
+def test_true_shape_layer(lib):
+    """One layer at the real LLaDA-8B widths (d 4096, 32 heads, FFN 12288), ragged sequence length."""
+    ocfg = OCfg(d_model=4096, n_layers=1, n_heads=32, mlp_hidden=12288, vocab_size=1024)
+    W = init_weights(ocfg, seed=3, std=0.02, head_scale=8.0)
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(1))
+    ids = g.integers(0, 1024, size=(2, 75), dtype=np.int64)
+    km = np.ones((2, 75), dtype=np.int64)
+    km[1, :9] = 0
+    got = model(torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(km).cuda()).logits.float().cpu().numpy()
+    ref = forward(W, ocfg, ids, km, emulate_bf16=True)
+    assert max_rel(got, ref) <= 2e-2, max_rel(got, ref)
+
+
+def test_generate_end_to_end(lib, tiny):
+    """llada_amd.generate on the HIP model vs the oracle sampler on the oracle model, temperature 0,
+    low_confidence: >= 99 % token-identical final sequences (the contract), batch with left padding."""
+    from llada_amd import generate
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(12))
+    B, P, G = 3, 10, 32
+    prompt = g.integers(0, ocfg.vocab_size, size=(B, P), dtype=np.int64)
+    am = np.ones((B, P), dtype=np.int64)
+    am[1, :3] = 0
+    om = OracleModel(W, ocfg, True)
+    same = total = 0
+    for (steps, bl, mask) in ((32, 8, am), (8, 32, None), (16, 16, am)):
+        out = generate(model, torch.from_numpy(prompt), None if mask is None else torch.from_numpy(mask), steps=steps,
+                       gen_length=G, block_length=bl, temperature=0., cfg_scale=0., remasking="low_confidence",
+                       mask_id=MASK_ID).cpu().numpy()
+        ref = osamp.generate(om, prompt, mask, steps=steps, gen_length=G, block_length=bl, temperature=0.0,
+                             cfg_scale=0.0, remasking="low_confidence", mask_id=MASK_ID)
+        assert np.array_equal(out[:, :P], prompt) and not (out == MASK_ID).any()
+        same += int((out == ref).sum())
+        total += out.size
+    assert same >= 0.99 * total, (same, total)
+
+
+def test_generate_cfg_gumbel_end_to_end(lib, tiny):
+    """CFG + temperature with injected noise: per-step teacher-forced agreement of the candidate
+    tokens on the positions both sides transfer (free-running sampling amplifies 1-ulp logit
+    differences, so the end-to-end check is per step)."""
+    from llada_amd import generate
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(13))
+    B, P, G, bl, steps = 2, 6, 16, 8, 8
+    prompt = g.integers(0, ocfg.vocab_size, size=(B, P), dtype=np.int64)
+    am = np.ones((B, P), dtype=np.int64)
+    seeds = iter(range(1000, 2000))
+    noise_log = []
+
+    def noise_fn(shape):
+        u = np.random.Generator(np.random.PCG64(next(seeds))).random(shape)
+        noise_log.append(u)
+        return torch.from_numpy(u)
+
+    out = generate(model, torch.from_numpy(prompt), torch.from_numpy(am), steps=steps, gen_length=G, block_length=bl,
+                   temperature=0.7, cfg_scale=1.0, remasking="low_confidence", mask_id=MASK_ID, noise_fn=noise_fn)
+    out = out.cpu().numpy()
+    assert not (out == MASK_ID).any() and np.array_equal(out[:, :P], prompt)
+    it = iter(noise_log)
+    ref = osamp.generate(OracleModel(W, ocfg, True), prompt, am, steps=steps, gen_length=G, block_length=bl,
+                         temperature=0.7, cfg_scale=1.0, remasking="low_confidence", mask_id=MASK_ID,
+                         noise_fn=lambda s: next(it))
+    assert (out == ref).mean() >= 0.9
+
+
+def test_likelihood_end_to_end(lib, tiny):
+    """llada_amd.get_log_likelihood on the HIP model vs the oracle on the oracle model with the same
+    masks: within 1e-3 relative (the contract)."""
+    from llada_amd import get_log_likelihood
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(14))
+    prompt = g.integers(0, ocfg.vocab_size, size=9, dtype=np.int64)
+    answer = g.integers(0, ocfg.vocab_size, size=15, dtype=np.int64)
+    for cfg_scale in (0.0, 0.5):
+        dg = np.random.Generator(np.random.PCG64(15))
+        ks = [int(dg.integers(1, 16)) for _ in range(4)]
+        perms = [dg.permutation(15) for _ in range(4 * 8)]
+        k1, p1 = list(ks), iter(perms)
+        val = get_log_likelihood(model, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=32, batch_size=8,
+                                 cfg_scale=cfg_scale, mask_id=MASK_ID, k_fn=lambda T: k1.pop(0),
+                                 perm_fn=lambda T: next(p1), round_ce_bf16=False)
+        k2, p2 = list(ks), iter(perms)
+        ref = oll.get_log_likelihood(OracleModel(W, ocfg, True), prompt, answer, mc_num=32, batch_size=8,
+                                     cfg_scale=cfg_scale, mask_id=MASK_ID, k_fn=lambda T: k2.pop(0),
+                                     perm_fn=lambda T: next(p2), round_to_bf16=False)
+        assert abs(val - ref) <= 1e-3 * abs(ref), (val, ref)
+    # library-RNG path runs and is reproducible
+    a = get_log_likelihood(model, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=16, batch_size=8, seed=5)
+    b = get_log_likelihood(model, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=16, batch_size=8, seed=5)
+    assert a == b and a < 0

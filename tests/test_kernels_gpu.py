@@ -1,0 +1,256 @@
+"""Per-kernel parity of the forward's building blocks (through the C ABI) against numpy
+restatements / the oracle, on a real MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import model as omodel
+from oracle.bf16 import round_bf16, ulp_distance
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def bf(a):
+    return dev(a.astype(np.float32), torch.bfloat16)
+
+
+def host(t):
+    return t.float().cpu().numpy()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(lib, rc):
+    assert rc == 0, lib.llada_last_error().decode()
+
+
+def gemm(lib, A, W, epi=0, R=None, cos=None, sin=None, seq_len=0, out_cols=None):
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.full((M, out_cols or N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rc = lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, K, out.shape[1], epi,
+                             None if R is None else R.data_ptr(), 0 if R is None else R.shape[1],
+                             None if cos is None else cos.data_ptr(), None if sin is None else sin.data_ptr(),
+                             seq_len, stream())
+    check(lib, rc)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("tile_rows", [0, 128, 192, 256])
+@pytest.mark.parametrize("shape", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (37, 264, 192), (777, 1024, 512)])
+def test_gemm_exact_integers(lib, shape, tile_rows):
+    """Small-integer operands make every float32 partial sum exact: the result must be bit-exact
+    whatever the tile shape, which pins the MFMA fragment maps, the LDS swizzle and the bounds."""
+    M, N, K = shape
+    g = np.random.Generator(np.random.PCG64(M * 7 + N))
+    A = g.integers(-3, 4, size=(M, K)).astype(np.float32)
+    W = g.integers(-3, 4, size=(N, K)).astype(np.float32)
+    lib.llada_gemm_force_tile_rows(tile_rows)
+    try:
+        out = host(gemm(lib, bf(A), bf(W)))
+    finally:
+        lib.llada_gemm_force_tile_rows(0)
+    ref = round_bf16(A @ W.T)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("shape", [(512, 512, 256), (3072, 1024, 4096), (130, 768, 1024)])
+def test_gemm_random(lib, shape):
+    M, N, K = shape
+    g = np.random.Generator(np.random.PCG64(11))
+    A = round_bf16(g.standard_normal((M, K), dtype=np.float32))
+    W = round_bf16(g.standard_normal((N, K), dtype=np.float32) * 0.05)
+    out = host(gemm(lib, bf(A), bf(W)))
+    ref = (A.astype(np.float64) @ W.T.astype(np.float64)).astype(np.float32)
+    err = np.abs(out - ref)
+    assert (err <= np.abs(ref) * 2.0 ** -8 + 1e-4 * np.sqrt(K)).all()
+
+
+def test_gemm_residual(lib):
+    M, N, K = 300, 512, 128
+    g = np.random.Generator(np.random.PCG64(5))
+    A = g.integers(-3, 4, size=(M, K)).astype(np.float32)
+    W = g.integers(-3, 4, size=(N, K)).astype(np.float32)
+    R = round_bf16(g.standard_normal((M, N), dtype=np.float32) * 10)
+    Rt = bf(R)
+    out = host(gemm(lib, bf(A), bf(W), epi=1, R=Rt))
+    ref = round_bf16(R + round_bf16(A @ W.T))
+    assert np.array_equal(out, ref)
+    # in place (C aliases R), as the forward uses it
+    rc = lib.llada_gemm_bf16(bf(A).data_ptr(), bf(W).data_ptr(), Rt.data_ptr(), M, N, K, K, N, 1, Rt.data_ptr(), N,
+                             None, None, 0, stream())
+    check(lib, rc)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(Rt), ref)
+
+
+def test_gemm_rope_epilogue(lib):
+    """Packed QKV projection + rotary embedding == natural projection followed by the oracle's rope."""
+    from llada_amd.weights import head_permutation, pack_qkv
+    n_seq, L, H = 2, 37, 2
+    d = H * 128
+    M = n_seq * L
+    g = np.random.Generator(np.random.PCG64(9))
+    A = round_bf16(g.standard_normal((M, d), dtype=np.float32))
+    Wq, Wk, Wv = (round_bf16(g.standard_normal((d, d), dtype=np.float32) * 0.06) for _ in range(3))
+    cos, sin = omodel.rope_tables(L, 128, 500000.0)
+    packed = pack_qkv(bf(Wq), bf(Wk), bf(Wv), H)
+    out = host(gemm(lib, bf(A), packed, epi=2, cos=dev(cos), sin=dev(sin), seq_len=L))
+    # exact float32 accumulation is order dependent: take the GPU's own plain projection as the input
+    nat = host(gemm(lib, bf(A), bf(np.concatenate([Wq, Wk, Wv]))))
+    q = nat[:, :d].reshape(n_seq, L, H, 128).transpose(0, 2, 1, 3)
+    k = nat[:, d:2 * d].reshape(n_seq, L, H, 128).transpose(0, 2, 1, 3)
+    qr = omodel.apply_rope(q, cos, sin, True).transpose(0, 2, 1, 3).reshape(M, H, 128)
+    kr = omodel.apply_rope(k, cos, sin, True).transpose(0, 2, 1, 3).reshape(M, H, 128)
+    perm = head_permutation()
+    assert np.array_equal(out[:, :d].reshape(M, H, 128), qr[:, :, perm])
+    assert np.array_equal(out[:, d:2 * d].reshape(M, H, 128), kr[:, :, perm])
+    assert np.array_equal(out[:, 2 * d:], nat[:, 2 * d:])
+
+
+def test_gemm_swiglu_epilogue(lib):
+    from llada_amd.weights import pack_gate_up
+    M, d, F = 200, 256, 384
+    g = np.random.Generator(np.random.PCG64(10))
+    A = round_bf16(g.standard_normal((M, d), dtype=np.float32))
+    Wg, Wu = (round_bf16(g.standard_normal((F, d), dtype=np.float32) * 0.08) for _ in range(2))
+    out = host(gemm(lib, bf(A), pack_gate_up(bf(Wg), bf(Wu)), epi=3, out_cols=F))
+    nat = host(gemm(lib, bf(A), bf(np.concatenate([Wg, Wu]))))
+    gate, up = nat[:, :F], nat[:, F:]
+    ref = round_bf16(round_bf16(gate / (np.float32(1) + np.exp(-gate))) * up)
+    assert ulp_distance(out, ref).max() <= 1
+    # and the unfused kernel on the natural layout
+    o2 = torch.empty((M, F), dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_swiglu_bf16(bf(nat).data_ptr(), o2.data_ptr(), M, F, stream()))
+    torch.cuda.synchronize()
+    assert ulp_distance(host(o2), ref).max() <= 1
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    a = torch.zeros(8, 96, dtype=torch.bfloat16, device="cuda")
+    rc = lib.llada_gemm_bf16(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 96, 96, 8, 0, None, 0, None, None, 0, None)
+    assert rc == -2 and b"K=" in lib.llada_last_error()
+
+
+@pytest.mark.parametrize("n_seq,L,H,masked", [(1, 64, 1, False), (2, 100, 2, False), (2, 384, 2, False),
+                                             (3, 200, 2, True), (1, 513, 1, True), (2, 31, 1, False)])
+def test_attention(lib, n_seq, L, H, masked):
+    d = H * 128
+    g = np.random.Generator(np.random.PCG64(L + H))
+    qkv = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
+    # spike a few keys so the running max jumps late in the sweep (exercises the rescale path)
+    qkv[L // 2, d:2 * d] *= 4
+    qkv[L - 1, d:2 * d] *= 6
+    km = None
+    if masked:
+        km = np.ones((n_seq, L), dtype=np.uint8)
+        for b in range(n_seq):
+            km[b, : 3 + 17 * b] = 0
+        km[0, L // 3: L // 3 + 70] = 0          # a whole 64-key tile masked
+    out = torch.full((n_seq * L, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    kmt = None if km is None else dev(km)
+    check(lib, lib.llada_attn_bidir_bf16(bf(qkv).data_ptr(), None if kmt is None else kmt.data_ptr(), out.data_ptr(),
+                                         n_seq, L, H, stream()))
+    torch.cuda.synchronize()
+    x = qkv.reshape(n_seq, L, 3, H, 128)
+    q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    ref = omodel.attention(q, k, v, km, False).transpose(0, 2, 1, 3).reshape(n_seq * L, d)
+    err = np.abs(host(out) - ref)
+    assert np.isfinite(host(out)).all()
+    assert err.max() <= 1.5e-2 * np.abs(ref).max(), err.max()
+
+
+def test_attention_exact_uniform(lib):
+    """All-equal scores: softmax is exactly uniform, so the output is the mean of V; with V
+    holding small integers over a power-of-two number of keys the result is exact in bf16."""
+    n_seq, L, H = 1, 128, 1
+    d = 128
+    g = np.random.Generator(np.random.PCG64(3))
+    qkv = np.zeros((L, 3 * d), dtype=np.float32)
+    qkv[:, 2 * d:] = g.integers(-8, 9, size=(L, d)) * 2.0
+    out = torch.empty((L, d), dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_attn_bidir_bf16(bf(qkv).data_ptr(), None, out.data_ptr(), n_seq, L, H, stream()))
+    torch.cuda.synchronize()
+    ref = round_bf16(np.repeat(qkv[:, 2 * d:].mean(axis=0, keepdims=True), L, axis=0))
+    assert np.array_equal(host(out), ref)
+
+
+def test_attention_v_layout(lib):
+    """One-hot attention (one huge key per query) returns that key's V row exactly: pins the
+    transposed V fragment map."""
+    L, d = 192, 128
+    g = np.random.Generator(np.random.PCG64(4))
+    qkv = np.zeros((L, 3 * d), dtype=np.float32)
+    target = g.permutation(L)
+    # query i = e_(i % 128) scaled, key j = e_(j % 128) scaled: q_i . k_j large iff same residue;
+    # break the residue tie with a second coordinate
+    for i in range(L):
+        qkv[i, i % 64] = 64.0
+        qkv[i, 64 + i // 64] = 64.0
+    for j in range(L):
+        i = int(np.where(target == j)[0][0])
+        qkv[j, d + i % 64] = 64.0
+        qkv[j, d + 64 + i // 64] = 64.0
+    qkv[:, 2 * d:] = round_bf16(g.standard_normal((L, d), dtype=np.float32))
+    out = torch.empty((L, d), dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_attn_bidir_bf16(bf(qkv).data_ptr(), None, out.data_ptr(), 1, L, 1, stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out), qkv[target, 2 * d:])
+
+
+@pytest.mark.parametrize("M,d", [(5, 256), (300, 4096), (17, 1024)])
+def test_rmsnorm(lib, M, d):
+    g = np.random.Generator(np.random.PCG64(d))
+    x = round_bf16(g.standard_normal((M, d), dtype=np.float32) * 3)
+    w = round_bf16(1 + 0.1 * g.standard_normal(d, dtype=np.float32))
+    out = torch.empty((M, d), dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_rmsnorm_bf16(bf(x).data_ptr(), bf(w).data_ptr(), out.data_ptr(), M, d, 1e-5, None, stream()))
+    torch.cuda.synchronize()
+    ref = omodel.rmsnorm(x, w, 1e-5, True)
+    assert ulp_distance(host(out), ref).max() <= 1
+    # gathered rows
+    idx = np.array([M - 1, 0, M // 2], dtype=np.int32)
+    out2 = torch.empty((3, d), dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_rmsnorm_bf16(bf(x).data_ptr(), bf(w).data_ptr(), out2.data_ptr(), 3, d, 1e-5,
+                                      dev(idx).data_ptr(), stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out2), host(out)[idx])
+
+
+def test_rope_kernel(lib):
+    n_seq, L, H = 2, 45, 2
+    d = H * 128
+    g = np.random.Generator(np.random.PCG64(8))
+    qkv = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
+    cos, sin = omodel.rope_tables(L, 128, 500000.0)
+    t = bf(qkv)
+    check(lib, lib.llada_rope_bf16(t.data_ptr(), dev(cos).data_ptr(), dev(sin).data_ptr(), n_seq, L, H, stream()))
+    torch.cuda.synchronize()
+    out = host(t)
+    for part in range(2):
+        a = qkv[:, part * d:(part + 1) * d].reshape(n_seq, L, H, 128).transpose(0, 2, 1, 3)
+        ref = omodel.apply_rope(a, cos, sin, True).transpose(0, 2, 1, 3).reshape(n_seq * L, d)
+        assert np.array_equal(out[:, part * d:(part + 1) * d], ref)
+    assert np.array_equal(out[:, 2 * d:], qkv[:, 2 * d:])
+
+
+def test_embed(lib):
+    V, d, n = 1000, 256, 77
+    g = np.random.Generator(np.random.PCG64(2))
+    wte = round_bf16(g.standard_normal((V, d), dtype=np.float32))
+    ids = g.integers(0, V, size=n, dtype=np.int64)
+    out = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_embed_bf16(bf(wte).data_ptr(), dev(ids).data_ptr(), out.data_ptr(), n, d, V, stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out), wte[ids])
