@@ -88,7 +88,8 @@ def test_gemm_residual(lib):
     ref = round_bf16(R + round_bf16(A @ W.T))
     assert np.array_equal(out, ref)
     # in place (C aliases R), as the forward uses it
-    rc = lib.llada_gemm_bf16(bf(A).data_ptr(), bf(W).data_ptr(), Rt.data_ptr(), M, N, K, K, N, 1, Rt.data_ptr(), N,
+    At, Wt = bf(A), bf(W)
+    rc = lib.llada_gemm_bf16(At.data_ptr(), Wt.data_ptr(), Rt.data_ptr(), M, N, K, K, N, 1, Rt.data_ptr(), N,
                              None, None, 0, stream())
     check(lib, rc)
     torch.cuda.synchronize()
@@ -132,7 +133,8 @@ def test_gemm_swiglu_epilogue(lib):
     assert ulp_distance(out, ref).max() <= 1
     # and the unfused kernel on the natural layout
     o2 = torch.empty((M, F), dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.llada_swiglu_bf16(bf(nat).data_ptr(), o2.data_ptr(), M, F, stream()))
+    natt = bf(nat)
+    check(lib, lib.llada_swiglu_bf16(natt.data_ptr(), o2.data_ptr(), M, F, stream()))
     torch.cuda.synchronize()
     assert ulp_distance(host(o2), ref).max() <= 1
 
@@ -160,7 +162,8 @@ def test_attention(lib, n_seq, L, H, masked):
         km[0, L // 3: L // 3 + 70] = 0          # a whole 64-key tile masked
     out = torch.full((n_seq * L, d), float("nan"), dtype=torch.bfloat16, device="cuda")
     kmt = None if km is None else dev(km)
-    check(lib, lib.llada_attn_bidir_bf16(bf(qkv).data_ptr(), None if kmt is None else kmt.data_ptr(), out.data_ptr(),
+    qt = bf(qkv)
+    check(lib, lib.llada_attn_bidir_bf16(qt.data_ptr(), None if kmt is None else kmt.data_ptr(), out.data_ptr(),
                                          n_seq, L, H, stream()))
     torch.cuda.synchronize()
     x = qkv.reshape(n_seq, L, 3, H, 128)
@@ -180,7 +183,8 @@ def test_attention_exact_uniform(lib):
     qkv = np.zeros((L, 3 * d), dtype=np.float32)
     qkv[:, 2 * d:] = g.integers(-8, 9, size=(L, d)) * 2.0
     out = torch.empty((L, d), dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.llada_attn_bidir_bf16(bf(qkv).data_ptr(), None, out.data_ptr(), n_seq, L, H, stream()))
+    qt = bf(qkv)
+    check(lib, lib.llada_attn_bidir_bf16(qt.data_ptr(), None, out.data_ptr(), n_seq, L, H, stream()))
     torch.cuda.synchronize()
     ref = round_bf16(np.repeat(qkv[:, 2 * d:].mean(axis=0, keepdims=True), L, axis=0))
     assert np.array_equal(host(out), ref)
@@ -204,7 +208,8 @@ def test_attention_v_layout(lib):
         qkv[j, d + 64 + i // 64] = 64.0
     qkv[:, 2 * d:] = round_bf16(g.standard_normal((L, d), dtype=np.float32))
     out = torch.empty((L, d), dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.llada_attn_bidir_bf16(bf(qkv).data_ptr(), None, out.data_ptr(), 1, L, 1, stream()))
+    qt = bf(qkv)
+    check(lib, lib.llada_attn_bidir_bf16(qt.data_ptr(), None, out.data_ptr(), 1, L, 1, stream()))
     torch.cuda.synchronize()
     assert np.array_equal(host(out), qkv[target, 2 * d:])
 
@@ -215,15 +220,16 @@ def test_rmsnorm(lib, M, d):
     x = round_bf16(g.standard_normal((M, d), dtype=np.float32) * 3)
     w = round_bf16(1 + 0.1 * g.standard_normal(d, dtype=np.float32))
     out = torch.empty((M, d), dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.llada_rmsnorm_bf16(bf(x).data_ptr(), bf(w).data_ptr(), out.data_ptr(), M, d, 1e-5, None, stream()))
+    xt, wt = bf(x), bf(w)
+    check(lib, lib.llada_rmsnorm_bf16(xt.data_ptr(), wt.data_ptr(), out.data_ptr(), M, d, 1e-5, None, stream()))
     torch.cuda.synchronize()
     ref = omodel.rmsnorm(x, w, 1e-5, True)
     assert ulp_distance(host(out), ref).max() <= 1
     # gathered rows
     idx = np.array([M - 1, 0, M // 2], dtype=np.int32)
     out2 = torch.empty((3, d), dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.llada_rmsnorm_bf16(bf(x).data_ptr(), bf(w).data_ptr(), out2.data_ptr(), 3, d, 1e-5,
-                                      dev(idx).data_ptr(), stream()))
+    it = dev(idx)
+    check(lib, lib.llada_rmsnorm_bf16(xt.data_ptr(), wt.data_ptr(), out2.data_ptr(), 3, d, 1e-5, it.data_ptr(), stream()))
     torch.cuda.synchronize()
     assert np.array_equal(host(out2), host(out)[idx])
 
@@ -235,7 +241,8 @@ def test_rope_kernel(lib):
     qkv = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
     cos, sin = omodel.rope_tables(L, 128, 500000.0)
     t = bf(qkv)
-    check(lib, lib.llada_rope_bf16(t.data_ptr(), dev(cos).data_ptr(), dev(sin).data_ptr(), n_seq, L, H, stream()))
+    ct, st = dev(cos), dev(sin)
+    check(lib, lib.llada_rope_bf16(t.data_ptr(), ct.data_ptr(), st.data_ptr(), n_seq, L, H, stream()))
     torch.cuda.synchronize()
     out = host(t)
     for part in range(2):
@@ -251,6 +258,7 @@ def test_embed(lib):
     wte = round_bf16(g.standard_normal((V, d), dtype=np.float32))
     ids = g.integers(0, V, size=n, dtype=np.int64)
     out = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.llada_embed_bf16(bf(wte).data_ptr(), dev(ids).data_ptr(), out.data_ptr(), n, d, V, stream()))
+    wt, it = bf(wte), dev(ids)
+    check(lib, lib.llada_embed_bf16(wt.data_ptr(), it.data_ptr(), out.data_ptr(), n, d, V, stream()))
     torch.cuda.synchronize()
     assert np.array_equal(host(out), wte[ids])

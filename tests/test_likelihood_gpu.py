@@ -56,9 +56,9 @@ def test_ll_mask_matches_reference(lib, case):
     for it, k in enumerate(z[f"{n}/k"]):
         counts = stratified_counts(int(k), b, l2).astype(np.int32)
         noisy = torch.empty((b, l1 + l2), dtype=torch.long, device="cuda")
-        check(lib, lib.llada_ll_mask(dev(seq).data_ptr(), noisy.data_ptr(), b, l1 + l2, l1, MASK_ID,
-                                     dev(counts).data_ptr(), dev(z[f"{n}/perms"][it].astype(np.int32)).data_ptr(),
-                                     0, it, 0, stream()))
+        st, ct, pt = dev(seq), dev(counts), dev(z[f"{n}/perms"][it].astype(np.int32))
+        check(lib, lib.llada_ll_mask(st.data_ptr(), noisy.data_ptr(), b, l1 + l2, l1, MASK_ID, ct.data_ptr(),
+                                     pt.data_ptr(), 0, it, 0, stream()))
         torch.cuda.synchronize()
         assert np.array_equal(noisy.cpu().numpy(), z[f"{n}/perturbed"][it])
 
@@ -101,9 +101,9 @@ def test_masked_ce_float32_mode(lib):
     row_loss = torch.empty(rows.size, dtype=torch.float32, device="cuda")
     out = torch.zeros(1, dtype=torch.float64, device="cuda")
     lgt = dev(lg.reshape(b * l, V)[rows], torch.bfloat16)
-    check(lib, lib.llada_masked_ce(lgt.data_ptr(), None, 0.0, dev(rows).data_ptr(), rows.size, V, dev(noisy).data_ptr(),
-                                   dev(seq).data_ptr(), b, l, MASK_ID, dev(pm).data_ptr(), 0, row_loss.data_ptr(),
-                                   out.data_ptr(), stream()))
+    rt, nt, st, pt = dev(rows), dev(noisy), dev(seq), dev(pm)
+    check(lib, lib.llada_masked_ce(lgt.data_ptr(), None, 0.0, rt.data_ptr(), rows.size, V, nt.data_ptr(), st.data_ptr(),
+                                   b, l, MASK_ID, pt.data_ptr(), 0, row_loss.data_ptr(), out.data_ptr(), stream()))
     torch.cuda.synchronize()
     lp = lg.astype(np.float64)
     lp = lp - np.log(np.exp(lp - lp.max(-1, keepdims=True)).sum(-1, keepdims=True)) - lp.max(-1, keepdims=True)
@@ -121,8 +121,9 @@ def test_ll_mask_philox(lib):
     seq = g.integers(0, 1000, size=(b, l), dtype=np.int64)
     counts = np.array([1, 7, T, 20, 33], dtype=np.int32)
     noisy = torch.empty((b, l), dtype=torch.long, device="cuda")
-    check(lib, lib.llada_ll_mask(dev(seq).data_ptr(), noisy.data_ptr(), b, l, l1, MASK_ID, dev(counts).data_ptr(), None,
-                                 seed, it, row_offset, stream()))
+    st, ct = dev(seq), dev(counts)
+    check(lib, lib.llada_ll_mask(st.data_ptr(), noisy.data_ptr(), b, l, l1, MASK_ID, ct.data_ptr(), None, seed, it,
+                                 row_offset, stream()))
     torch.cuda.synchronize()
     keys = orng.ll_sort_keys(seed, it, row_offset + np.arange(b), T)
     want = seq.copy()

@@ -50,14 +50,25 @@ def remask(lib, cond, un, cfg, x, block_end, remasking, flags, T, noise=None, ra
     return x0.cpu().numpy(), conf.cpu().numpy()
 
 
-def compare_conf(got, ref, exact):
+def assert_x0(x0, ox0, oconf, x):
+    """Candidate tokens agree wherever they can be used (confidence > -inf); elsewhere the
+    kernel keeps x0 = x (the reference computes an argmax there that nothing reads)."""
+    live = ~np.isneginf(oconf)
+    assert np.array_equal(x0[live], ox0[live])
+    assert np.array_equal(x0[~live], x[~live])
+
+
+def compare_conf(got, ref, exact, abs_tol=0.0):
+    """-inf / NaN patterns identical; finite values within 1 bf16 ulp (or abs_tol: the entropy of a
+    nearly one-hot row is ~log(1 + eps) of a float32 sum and inherits that sum's last-bit noise)."""
     assert np.array_equal(np.isneginf(got), np.isneginf(ref))
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     fin = np.isfinite(ref)
     if exact:
         assert np.array_equal(got[fin], ref[fin])
     else:
-        assert ulp_distance(got[fin], ref[fin]).max(initial=0) <= 1
+        bad = (ulp_distance(got[fin], ref[fin]) > 1) & (np.abs(got[fin] - ref[fin]) > abs_tol)
+        assert not bad.any()
 
 
 def _cases():
@@ -99,15 +110,16 @@ def test_remask_step_teacher_forced(lib, case, sampler_z):
         logits = osamp.cfg_combine(lg[:B], lg[B:], case["cfg"]) if case["cfg"] > 0 else lg.copy()
         ox0, oconf = osamp.confidence_step(xs[t], logits, MASK_ID, be, case["remasking"], case["T"], u, rs,
                                            case["eos_inf"], case["conf_inf"])
-        assert np.array_equal(x0, ox0)
-        compare_conf(conf, oconf, exact=case["remasking"] == "random")
+        assert_x0(x0, ox0, oconf, xs[t])
+        compare_conf(conf, oconf, exact=case["remasking"] == "random", abs_tol=4e-7 if entropy else 0.0)
         if not entropy:   # the golden entropy values carry torch's CPU-only log_softmax rounding
             compare_conf(conf, conf_ref[t], exact=case["remasking"] == "random")
         # top-k transfer on the reference's own confidence tensor
         xt = dev(xs[t].copy())
         sched = dev(ks[t].astype(np.int32).reshape(B, 1))
-        check(lib, lib.llada_topk_transfer(xt.data_ptr(), dev(ox0).data_ptr(), dev(conf_ref[t].astype(np.float32)).data_ptr(),
-                                           B, L, sched.data_ptr(), 1, 0, stream()))
+        x0t, cft = dev(ox0), dev(conf_ref[t].astype(np.float32))
+        check(lib, lib.llada_topk_transfer(xt.data_ptr(), x0t.data_ptr(), cft.data_ptr(), B, L, sched.data_ptr(), 1, 0,
+                                           stream()))
         torch.cuda.synchronize()
         x_new = xt.cpu().numpy()
         want = xs[t].copy()
@@ -141,7 +153,7 @@ def test_remask_rows_subset_and_defaults(lib):
     lg_full = fake_model_logits(3, 0, (B, L, V))
     x0, conf = remask(lib, lg_full.reshape(B * L, V)[rows], None, 0.0, x, P + bl, "low_confidence", 0, 0.0, row_pos=rows)
     ox0, oconf = osamp.confidence_step(x, lg_full.copy(), MASK_ID, P + bl, "low_confidence")
-    assert np.array_equal(x0, ox0)
+    assert_x0(x0, ox0, oconf, x)
     compare_conf(conf, oconf, exact=False)
     assert np.isneginf(conf[:, P + bl:]).all() and np.isneginf(conf[:, :P]).all() and np.isneginf(conf[1, P + 3])
 
@@ -160,7 +172,7 @@ def test_remask_philox_streams(lib, remasking):
     u = orng.gumbel_uniforms(seed, step, row_offset + np.arange(B), np.arange(L), V)
     rs = orng.remask_uniforms(seed, step, row_offset + np.arange(B), np.arange(L))
     ox0, oconf = osamp.confidence_step(x, lg.copy(), MASK_ID, L, remasking, 0.7, u, rs)
-    assert np.array_equal(x0, ox0)
+    assert_x0(x0, ox0, oconf, x)
     compare_conf(conf, oconf, exact=remasking == "random")
 
 
@@ -175,7 +187,7 @@ def test_remask_full_vocab(lib):
                           None if u is None else u.reshape(B * L, V))
         logits = osamp.cfg_combine(lg[:B], lg[B:], 1.0)
         ox0, oconf = osamp.confidence_step(x, logits, MASK_ID, L, "low_confidence", T, u, None, True, True)
-        assert np.array_equal(x0, ox0)
+        assert_x0(x0, ox0, oconf, x)
         compare_conf(conf, oconf, exact=False)
 
 
@@ -188,7 +200,8 @@ def test_num_transfer_tokens(lib):
     x[3, 5:45] = MASK_ID
     for steps in (1, 3, 8, 20):
         sched = torch.empty((B, steps), dtype=torch.int32, device="cuda")
-        check(lib, lib.llada_num_transfer_tokens(dev(x).data_ptr(), B, L, 10, 30, MASK_ID, steps, sched.data_ptr(), stream()))
+        xt = dev(x)
+        check(lib, lib.llada_num_transfer_tokens(xt.data_ptr(), B, L, 10, 30, MASK_ID, steps, sched.data_ptr(), stream()))
         torch.cuda.synchronize()
         ref = osamp.get_num_transfer_tokens(x[:, 10:30] == MASK_ID, steps)
         assert np.array_equal(sched.cpu().numpy(), ref)
@@ -210,8 +223,8 @@ def test_topk_edge_cases(lib):
     x = np.zeros((5, L), dtype=np.int64)
     x0 = np.arange(5 * L, dtype=np.int64).reshape(5, L) + 1
     xt = dev(x.copy())
-    check(lib, lib.llada_topk_transfer(xt.data_ptr(), dev(x0).data_ptr(), dev(conf).data_ptr(), 5, L,
-                                       dev(ks.reshape(5, 1)).data_ptr(), 1, 0, stream()))
+    x0t, cft, kst = dev(x0), dev(conf), dev(ks.reshape(5, 1))
+    check(lib, lib.llada_topk_transfer(xt.data_ptr(), x0t.data_ptr(), cft.data_ptr(), 5, L, kst.data_ptr(), 1, 0, stream()))
     torch.cuda.synchronize()
     got = xt.cpu().numpy()
     want = x.copy()
