@@ -33,6 +33,8 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int seq_len;
     int rope_cols;  // columns < rope_cols get the rotary embedding (2 * d_model)
+    int band_m;     // M tiles per band of the tile walk
+    int remap;      // 1: XCD-aware block -> tile map
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -45,10 +47,10 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_uni
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
 // tiles, and walk the tiles in bands of 8 M-tiles so the 32 tiles resident on an XCD share
 // their A rows and W rows through that XCD's L2.  Bijective for any tile count.
-__device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int tiles_n, int& tm, int& tn,
+                                              int GM = 8, int remap = 1) {
     const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GM = 8;
+    const int wg = remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     const int band = wg / (GM * tiles_n);
     const int first_m = band * GM;
     const int rows = min(GM, tiles_m - first_m);
@@ -57,86 +59,10 @@ __device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int 
     tn = in_band / rows;
 }
 
+// Epilogue shared by both main loops: the lane holds C[m][n .. n+3] for m = row(mf), n = col(nf).
 template <int MFR, int EPI>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BM = MFR * 32;
-    constexpr int A_BYTES = BM * ROW_BYTES;
-    constexpr int B_BYTES = BN * ROW_BYTES;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_LOADS = BM / 64;  // 16-byte DMA instructions per wave per stage
-    constexpr int B_LOADS = BN / 64;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    int tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- per-lane DMA source addresses (row clamped into the matrix; chunk pre-swizzled) ----
-    const bf16_t* a_src[A_LOADS];
-    const bf16_t* b_src[B_LOADS];
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int grow = min(m0 + row, p.M - 1);
-        a_src[i] = p.A + (size_t)grow * p.lda + chunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int grow = min(n0 + row, p.N - 1);
-        b_src[i] = p.W + (size_t)grow * p.K + chunk * 8;
-    }
-
-    auto stage = [&](int s, int kt) {
-        unsigned char* base = smem + s * STAGE;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) glds16(a_src[i] + kt * BK, base + (i * 8 + wave) * 1024);
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) glds16(b_src[i] + kt * BK, base + A_BYTES + (i * 8 + wave) * 1024);
-    };
-
-    f32x4 acc[MFR][4];
-#pragma unroll
-    for (int i = 0; i < MFR; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const int swz = fr >> 1;
-    const int a_row_off = (wm * MFR * 16 + fr) * ROW_BYTES;
-    const int b_row_off = (wn * 64 + fr) * ROW_BYTES;
-
-    const int nk = p.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // stage kt has landed (vmcnt(0) + barrier); everyone is done with the other stage
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const unsigned char* As = smem + (kt & 1) * STAGE;
-        const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fq) ^ swz) * 16;
-            bf16x8 af[MFR], wf[4];
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) wf[nf] = *(const bf16x8*)(Bs + b_row_off + nf * 16 * ROW_BYTES + coff);
-#pragma unroll
-            for (int mf = 0; mf < MFR; ++mf) af[mf] = *(const bf16x8*)(As + a_row_off + mf * 16 * ROW_BYTES + coff);
-#pragma unroll
-            for (int mf = 0; mf < MFR; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], af[mf], acc[mf][nf], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: lane holds C[m][n .. n+3], m = row(mf) , n = col(nf) ----
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR][4], int m0, int n0, int wm, int wn,
+                                           int fr, int fq) {
     const int m_base = m0 + wm * MFR * 16 + fr;
     const int n_base = n0 + wn * 64 + fq * 4;
     if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
@@ -226,6 +152,281 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
 }
 
 template <int MFR, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = MFR * 32;
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int B_BYTES = BN * ROW_BYTES;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_LOADS = BM / 64;  // 16-byte DMA instructions per wave per stage
+    constexpr int B_LOADS = BN / 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane DMA source addresses (row clamped into the matrix; chunk pre-swizzled) ----
+    const bf16_t* a_src[A_LOADS];
+    const bf16_t* b_src[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int grow = min(m0 + row, p.M - 1);
+        a_src[i] = p.A + (size_t)grow * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int grow = min(n0 + row, p.N - 1);
+        b_src[i] = p.W + (size_t)grow * p.K + chunk * 8;
+    }
+
+    auto stage = [&](int s, int kt) {
+        unsigned char* base = smem + s * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) glds16(a_src[i] + kt * BK, base + (i * 8 + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) glds16(b_src[i] + kt * BK, base + A_BYTES + (i * 8 + wave) * 1024);
+    };
+
+    f32x4 acc[MFR][4];
+#pragma unroll
+    for (int i = 0; i < MFR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = fr >> 1;
+    const int a_row_off = (wm * MFR * 16 + fr) * ROW_BYTES;
+    const int b_row_off = (wn * 64 + fr) * ROW_BYTES;
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // stage kt has landed (vmcnt(0) + barrier); everyone is done with the other stage
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* As = smem + (kt & 1) * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ swz) * 16;
+            bf16x8 af[MFR], wf[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) wf[nf] = *(const bf16x8*)(Bs + b_row_off + nf * 16 * ROW_BYTES + coff);
+#pragma unroll
+            for (int mf = 0; mf < MFR; ++mf) af[mf] = *(const bf16x8*)(As + a_row_off + mf * 16 * ROW_BYTES + coff);
+#pragma unroll
+            for (int mf = 0; mf < MFR; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], af[mf], acc[mf][nf], 0, 0, 0);
+        }
+    }
+
+    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Main kernel: the same tile, but the K loop is software-pipelined in quarter-tile phases so that
+// no wave ever drains its LDS-DMA queue.
+//
+// Each 64-deep K tile is staged as four regions (A half 0/1 = the lower/upper half of every wave's
+// rows, B half 0/1 = the lower/upper 32 of every wave's 64 columns) and consumed in four phases,
+// one output quadrant each: (A0,B0) (A1,B0) (A1,B1) (A0,B1).  A phase
+//   1. re-issues the DMA of the region whose fragments were read in the previous phase, for the
+//      tile two steps ahead (so every region has ~7 phases = 1.75 K tiles to land),
+//   2. reads from LDS the fragments the NEXT phase needs (register sets X/Y for the A halves, P/Q
+//      for the B halves; A0 alternates between X and Y from tile to tile, hence two tiles per loop
+//      iteration),
+//   3. issues its quadrant's MFMAs from registers read one phase earlier,
+//   4. waits for its own LDS reads (lgkmcnt(0)) and, with a COUNTED vmcnt, for its share of the
+//      region the next phase reads, then joins the workgroup barrier (raw s_barrier: no drain).
+// Data staged by DMA is therefore read one phase after the wait + barrier that retire it, and a
+// region is refilled only after the barrier that follows its last read.
+// The vmcnt counts assume every phase issues its region, so past the last K tile the phases keep
+// issuing loads (of tile nk-1, into regions nobody reads again).
+template <int MFR, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = MFR * 32;
+    constexpr int HA = MFR / 2;                 // m fragments per A half (per wave)
+    constexpr int AH_ROWS = MFR * 16;           // rows of one A-half region (both wave rows)
+    constexpr int AH_BYTES = AH_ROWS * ROW_BYTES;
+    constexpr int BH_BYTES = 128 * ROW_BYTES;   // 4 waves x 32 columns
+    constexpr int STAGE = 2 * AH_BYTES + 2 * BH_BYTES;
+    constexpr int A_GROUPS = AH_ROWS / 8;       // 1-KiB DMA pieces per A-half region: 8, 12 or 16
+    constexpr int NB = 2;                       // pieces per wave per B-half region
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool two_a = (wave + 8) < A_GROUPS;   // this wave moves a second A piece per region (wave-uniform)
+
+    int tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA sources: region-local row rho -> tile row; chunk pre-swizzled by the local row ----
+    const bf16_t* a_src[2][2];
+    const bf16_t* b_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            {
+                const int g = min(wave + 8 * u, A_GROUPS - 1);
+                const int rho = g * 8 + (lane >> 3);
+                const int trow = (rho / (MFR * 8)) * (MFR * 16) + h * (MFR * 8) + rho % (MFR * 8);
+                const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+                a_src[h][u] = p.A + (size_t)min(m0 + trow, p.M - 1) * p.lda + chunk * 8;
+            }
+            {
+                const int g = wave + 8 * u;
+                const int rho = g * 8 + (lane >> 3);
+                const int tcol = (rho >> 5) * 64 + h * 32 + (rho & 31);
+                const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+                b_src[h][u] = p.W + (size_t)min(n0 + tcol, p.N - 1) * p.K + chunk * 8;
+            }
+        }
+
+    const int nk = p.K / BK;
+    auto issue_a = [&](int h, int tt) {
+        const int ks = min(tt, nk - 1) * BK;
+        unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES;
+        glds16(a_src[h][0] + ks, base + wave * 1024);
+        if (two_a) glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
+    };
+    auto issue_b = [&](int h, int tt) {
+        const int ks = min(tt, nk - 1) * BK;
+        unsigned char* base = smem + (tt & 1) * STAGE + 2 * AH_BYTES + h * BH_BYTES;
+        glds16(b_src[h][0] + ks, base + wave * 1024);
+        glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = fr >> 1;
+    const int c0 = ((0 + fq) ^ swz) * 16, c1 = ((4 + fq) ^ swz) * 16;
+    const int a_off = (wm * (MFR * 8) + fr) * ROW_BYTES;
+    const int b_off = 2 * AH_BYTES + (wn * 32 + fr) * ROW_BYTES;
+
+    auto read_a = [&](bf16x8 (&r)[HA][2], int h, int tt) {
+        const unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES + a_off;
+#pragma unroll
+        for (int mf = 0; mf < HA; ++mf) {
+            r[mf][0] = *(const bf16x8*)(base + mf * 16 * ROW_BYTES + c0);
+            r[mf][1] = *(const bf16x8*)(base + mf * 16 * ROW_BYTES + c1);
+        }
+    };
+    auto read_b = [&](bf16x8 (&r)[2][2], int h, int tt) {
+        const unsigned char* base = smem + (tt & 1) * STAGE + h * BH_BYTES + b_off;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            r[nf][0] = *(const bf16x8*)(base + nf * 16 * ROW_BYTES + c0);
+            r[nf][1] = *(const bf16x8*)(base + nf * 16 * ROW_BYTES + c1);
+        }
+    };
+
+    f32x4 acc[MFR][4];
+#pragma unroll
+    for (int i = 0; i < MFR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[2][2], int ha, int hb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mf = 0; mf < HA; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    acc[ha * HA + mf][hb * 2 + nf] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a[mf][ks], acc[ha * HA + mf][hb * 2 + nf], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // A phase = [refill + LDS reads] barrier [MFMAs] barrier.  Waves 4-7 (the upper half of the tile
+    // rows, which share their SIMDs with waves 0-3) run one barrier behind waves 0-3, so between two
+    // barriers one wave of every SIMD issues MFMAs while its partner issues its DMA and LDS reads.
+    // Before the second barrier a wave waits for its own LDS reads and, with a COUNTED vmcnt, for
+    // its share of the region that is read two phases on (the other half confirms its share one
+    // interval later, and only then may anyone read it): two B and two A regions are younger.
+    // A region is refilled two phases after it was read, i.e. after both halves have confirmed
+    // their reads of it.
+#define WAIT_END(n_b, n_a)                                                                            \
+    do {                                                                                              \
+        if (two_a)                                                                                    \
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((n_b) * NB + (n_a) * 2) : "memory");  \
+        else                                                                                          \
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((n_b) * NB + (n_a) * 1) : "memory");  \
+    } while (0)
+#define BARRIER()                           \
+    do {                                    \
+        __builtin_amdgcn_s_barrier();       \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+#define PHASE(issue_stmt, read_stmt, mma_stmt)  \
+    do {                                        \
+        issue_stmt;                             \
+        read_stmt;                              \
+        BARRIER();                              \
+        mma_stmt;                               \
+        WAIT_END(2, 2);                         \
+        BARRIER();                              \
+    } while (0)
+
+    bf16x8 X[HA][2], Y[HA][2], P[2][2], Q[2][2];
+
+    // ---- prologue: tiles 0 and 1 in flight, in the order B0 A0 A1 B1 ----
+    issue_b(0, 0);
+    issue_a(0, 0);
+    issue_a(1, 0);
+    issue_b(1, 0);
+    issue_b(0, 1);
+    issue_a(0, 1);
+    issue_a(1, 1);
+    issue_b(1, 1);
+    WAIT_END(3, 3);         // B0(0), A0(0) landed: A1(0) B1(0) B0(1) A0(1) A1(1) B1(1) are younger
+    BARRIER();
+    read_a(X, 0, 0);
+    read_b(P, 0, 0);
+    WAIT_END(2, 2);         // own reads done; A1(0), B1(0) landed: B0(1) A0(1) A1(1) B1(1) are younger
+    BARRIER();
+    if (wm == 1) BARRIER(); // stagger: the upper half runs one barrier behind
+
+    for (int t = 0; t < nk; t += 2) {
+        // ---- even tile t: A0 in X, A1 -> Y ----
+        PHASE(issue_b(0, t + 2), read_a(Y, 1, t),     mma(X, P, 0, 0));
+        PHASE(issue_a(0, t + 2), read_b(Q, 1, t),     mma(Y, P, 1, 0));
+        PHASE(issue_a(1, t + 2), read_b(P, 0, t + 1), mma(Y, Q, 1, 1));
+        PHASE(issue_b(1, t + 2), read_a(Y, 0, t + 1), mma(X, Q, 0, 1));
+        // ---- odd tile t+1: A0 in Y, A1 -> X ----
+        PHASE(issue_b(0, t + 3), read_a(X, 1, t + 1), mma(Y, P, 0, 0));
+        PHASE(issue_a(0, t + 3), read_b(Q, 1, t + 1), mma(X, P, 1, 0));
+        PHASE(issue_a(1, t + 3), read_b(P, 0, t + 2), mma(X, Q, 1, 1));
+        PHASE(issue_b(1, t + 3), read_a(X, 0, t + 2), mma(Y, Q, 0, 1));
+    }
+    if (wm == 0) BARRIER(); // the lower half waits for the upper half's last interval
+#undef WAIT_END
+#undef PHASE
+#undef BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills must land before the LDS is released
+
+    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq);
+}
+
+int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel
+int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
+
+template <int MFR, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = MFR * 32;
     constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
@@ -240,9 +441,29 @@ int launch(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     GemmParams q = p;
+    q.band_m = g_band_m;
+    q.remap = g_remap;
     q.tiles_m = (int)((p.M + BM - 1) / BM);
     q.tiles_n = (p.N + BN - 1) / BN;
     const int nt = q.tiles_m * q.tiles_n;
+    const int nk = p.K / BK;
+    if constexpr (MFR != 8) {  // the 256-row tile does not fit the pipelined kernel's register budget
+      if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+                return LLADA_ERR_HIP;
+            }
+            attr2_set = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI>), dim3(nt), dim3(NTHREADS), lds, stream, q);
+        LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
+        return LLADA_OK;
+      }
+    }
     hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(nt), dim3(NTHREADS), lds, stream, q);
     LLADA_CHECK_LAUNCH("gemm_bf16_kernel");
     return LLADA_OK;
@@ -260,8 +481,10 @@ int pick_mfr(int64_t M, int N) {
         const int64_t tiles_m = (M + bm - 1) / bm;
         const int64_t nt = tiles_m * tiles_n;
         const int64_t rounds = (nt + 255) / 256;
-        // time ~ rounds * (tile work); smaller tiles pay a little more per flop (operand traffic)
-        const double cost = (double)rounds * bm * (c == 8 ? 1.0 : (c == 6 ? 1.03 : 1.10));
+        // time ~ rounds * (tile work) * a per-tile efficiency factor: the 192-row tile runs the
+        // pipelined main loop at the best rate, 128 rows re-read more operand bytes per flop, 256
+        // rows only has the simple two-stage loop
+        const double cost = (double)rounds * bm * (c == 8 ? 1.10 : (c == 6 ? 1.0 : 1.08));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -284,6 +507,11 @@ int dispatch_mfr(const GemmParams& p, int mfr, hipStream_t stream) {
 // Test hook: force the M tile (0 = automatic).
 static int g_force_mfr = 0;
 extern "C" void llada_gemm_force_tile_rows(int rows) { g_force_mfr = rows / 32; }
+extern "C" void llada_gemm_use_pipelined(int on) { g_use_pipelined = on; }
+extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
+    g_band_m = band_m > 0 ? band_m : 8;
+    g_remap = remap;
+}
 
 // Measurement hook (bench.py): while active, every launch of the GEMM with the chosen epilogue is
 // bracketed by a pair of HIP events on the launch stream, so the kernel's average duration inside

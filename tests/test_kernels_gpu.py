@@ -48,7 +48,8 @@ def gemm(lib, A, W, epi=0, R=None, cos=None, sin=None, seq_len=0, out_cols=None)
 
 
 @pytest.mark.parametrize("tile_rows", [0, 128, 192, 256])
-@pytest.mark.parametrize("shape", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (37, 264, 192), (777, 1024, 512)])
+@pytest.mark.parametrize("shape", [(256, 256, 64), (300, 512, 128), (1000, 768, 256), (37, 264, 192), (777, 1024, 512),
+                                   (1111, 520, 1024), (400, 256, 384)])
 def test_gemm_exact_integers(lib, shape, tile_rows):
     """Small-integer operands make every float32 partial sum exact: the result must be bit-exact
     whatever the tile shape, which pins the MFMA fragment maps, the LDS swizzle and the bounds."""
@@ -63,6 +64,26 @@ def test_gemm_exact_integers(lib, shape, tile_rows):
         lib.llada_gemm_force_tile_rows(0)
     ref = round_bf16(A @ W.T)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("tile_rows", [128, 192])
+def test_gemm_pipelined_equals_simple(lib, tile_rows):
+    """The quarter-tile pipelined main loop and the simple two-stage loop accumulate every output in
+    the same k order: bit-identical results on random data, ragged M and N, long K."""
+    M, N, K = 1000, 776, 2048
+    g = np.random.Generator(np.random.PCG64(21))
+    A = bf(round_bf16(g.standard_normal((M, K), dtype=np.float32)))
+    W = bf(round_bf16(g.standard_normal((N, K), dtype=np.float32) * 0.05))
+    lib.llada_gemm_use_pipelined.argtypes = [C.c_int]
+    lib.llada_gemm_force_tile_rows(tile_rows)
+    try:
+        fast = gemm(lib, A, W)
+        lib.llada_gemm_use_pipelined(0)
+        slow = gemm(lib, A, W)
+    finally:
+        lib.llada_gemm_use_pipelined(1)
+        lib.llada_gemm_force_tile_rows(0)
+    assert torch.equal(fast, slow)
 
 
 @pytest.mark.parametrize("shape", [(512, 512, 256), (3072, 1024, 4096), (130, 768, 1024)])
