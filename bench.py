@@ -100,10 +100,6 @@ def main():
     cfg = LLaDAConfig(n_layers=args.layers)
     model = LLaDAModel(LLaDAWeights.random(cfg, device, seed=0))
     lib = _lib.load()
-    lib.llada_gemm_profile_begin.restype = C.c_int
-    lib.llada_gemm_profile_begin.argtypes = [C.c_int, C.c_int]
-    lib.llada_gemm_profile_end.restype = C.c_int
-    lib.llada_gemm_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
     B, P, G, bl = args.batch, args.prompt, args.gen, args.block
     L = P + G

@@ -123,10 +123,15 @@ int llada_rmsnorm_bf16(const void* x, const void* w, void* out, int64_t n_rows, 
 /* C[M, N] = A[M, K] @ W[N, K]^T on bf16 MFMA with float32 accumulation.  lda/ldc/ldr are row
  * strides in elements.  K % 64 == 0 and N % 8 == 0 are required.  aux: residual R [M, N]
  * (EPI_RESIDUAL, row stride ldr), or NULL.  For EPI_ROPE_QKV pass rope_cos/rope_sin
- * [seq_len, 64] float32, seq_len and d_model (= N / 3); for EPI_SWIGLU C is [M, N/2]. */
+ * [seq_len, 64] float32, seq_len and d_model (= N / 3); for EPI_SWIGLU C is [M, N/2].
+ * workspace (may be NULL): float32 scratch for split-K partial sums; when M is so small that the
+ * output tiles would leave most CUs idle, K is cut into ranges summed by a second pass, in a
+ * fixed order.  llada_gemm_workspace_bytes gives the size that removes every limit. */
 int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int32_t N, int32_t K, int32_t lda,
                     int32_t ldc, int32_t epilogue, const void* aux, int32_t ldr, const float* rope_cos,
-                    const float* rope_sin, int32_t seq_len, void* stream);
+                    const float* rope_sin, int32_t seq_len, void* workspace, size_t workspace_bytes,
+                    void* stream);
+size_t llada_gemm_workspace_bytes(int64_t M, int32_t N, int32_t K);
 
 /* In-place rotary embedding of the Q and K thirds of qkv [n_seq*seq_len, 3*d] (natural head
  * layout, pairs (j, j+64)); float32 arithmetic, bf16 result. */

@@ -51,7 +51,8 @@ SIGNATURES = {
     "llada_embed_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp, vp]),
     "llada_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
-                                  C.c_int32, vp, vp, C.c_int32, vp]),
+                                  C.c_int32, vp, vp, C.c_int32, vp, C.c_size_t, vp]),
+    "llada_gemm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "llada_rope_bf16": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
     "llada_swiglu_bf16": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp]),
     "llada_attn_bidir_bf16": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
@@ -65,7 +66,10 @@ SIGNATURES = {
                                   C.c_int64, vp, C.c_int32, vp, vp, vp]),
 }
 # test hooks outside the public header
-_EXTRA = {"llada_gemm_force_tile_rows": (None, [C.c_int])}
+_EXTRA = {"llada_gemm_force_tile_rows": (None, [C.c_int]), "llada_gemm_use_pipelined": (None, [C.c_int]),
+          "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]),
+          "llada_gemm_profile_begin": (C.c_int, [C.c_int, C.c_int]),
+          "llada_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)])}
 
 _lib = None
 

@@ -11,7 +11,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t x, h, qkv, att, act, gu, hf, total;
+    size_t x, h, qkv, att, act, gu, hf, splitk, splitk_bytes, total;
 };
 
 Layout make_layout(const llada_config& c, int64_t M, int64_t R) {
@@ -30,6 +30,16 @@ Layout make_layout(const llada_config& c, int64_t M, int64_t R) {
     o.act = take(M * F * 2);
     o.gu = take(M * 2 * F * 2);
     o.hf = take(R * d * 2);
+    // split-K scratch for the small-M regime (every projection of a layer, and the LM head)
+    size_t sk = 0;
+    const size_t shapes[5][3] = {{(size_t)M, 3 * d, d}, {(size_t)M, d, d}, {(size_t)M, 2 * F, d}, {(size_t)M, d, F},
+                                 {(size_t)R, (size_t)c.vocab_size, d}};
+    for (auto& sh : shapes) {
+        const size_t b = llada_gemm_workspace_bytes((int64_t)sh[0], (int32_t)sh[1], (int32_t)sh[2]);
+        sk = b > sk ? b : sk;
+    }
+    o.splitk_bytes = sk;
+    o.splitk = take(sk);
     o.total = off;
     return o;
 }
@@ -73,6 +83,8 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     void* act = ws + lay.act;
     void* gu = ws + lay.gu;
     void* hf = ws + lay.hf;
+    void* sk = lay.splitk_bytes ? ws + lay.splitk : nullptr;
+    const size_t skb = lay.splitk_bytes;
     const int d = c.d_model, F = c.mlp_hidden, V = c.vocab_size;
 
     TRY(llada_embed_bf16(w->wte, ids, x, M, d, V, stream));
@@ -80,28 +92,28 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
         TRY(llada_rmsnorm_bf16(x, w->attn_norm[l], h, M, d, c.rms_eps, nullptr, stream));
         if (w->packed) {
             TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, rope_cos,
-                                rope_sin, seq_len, stream));
+                                rope_sin, seq_len, sk, skb, stream));
         } else {
             TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
-                                nullptr, 0, stream));
+                                nullptr, 0, sk, skb, stream));
             TRY(llada_rope_bf16(qkv, rope_cos, rope_sin, n_seq, seq_len, c.n_heads, stream));
         }
         TRY(llada_attn_bidir_bf16(qkv, key_mask, att, n_seq, seq_len, c.n_heads, stream));
-        TRY(llada_gemm_bf16(att, w->wo[l], x, M, d, d, d, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0, stream));
+        TRY(llada_gemm_bf16(att, w->wo[l], x, M, d, d, d, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0, sk, skb, stream));
         TRY(llada_rmsnorm_bf16(x, w->ff_norm[l], h, M, d, c.rms_eps, nullptr, stream));
         if (w->packed) {
             TRY(llada_gemm_bf16(h, w->wgu[l], act, M, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr,
-                                0, stream));
+                                0, sk, skb, stream));
         } else {
             TRY(llada_gemm_bf16(h, w->wgu[l], gu, M, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
-                                nullptr, 0, stream));
+                                nullptr, 0, sk, skb, stream));
             TRY(llada_swiglu_bf16(gu, act, M, F, stream));
         }
         TRY(llada_gemm_bf16(act, w->wdown[l], x, M, d, F, F, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0,
-                            stream));
+                            sk, skb, stream));
     }
     TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, n_logit_rows, d, c.rms_eps, logit_rows, stream));
     TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, n_logit_rows, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
-                        nullptr, 0, stream));
+                        nullptr, 0, sk, skb, stream));
     return LLADA_OK;
 }

@@ -20,6 +20,7 @@ constexpr int BN = 256;
 constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int ROW_BYTES = BK * 2;  // 128
+constexpr int EPI_PARTIAL = 100;   // internal: float32 partial tile of a split-K launch
 
 struct GemmParams {
     const bf16_t* A;
@@ -33,6 +34,9 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int seq_len;
     int rope_cols;  // columns < rope_cols get the rotary embedding (2 * d_model)
+    float* slab;    // split-K partial sums [splits][M][N] float32, or nullptr
+    int splits;     // K is cut into `splits` equal ranges, one workgroup each per output tile
+    int n_tiles;    // tiles_m * tiles_n
     int band_m;     // M tiles per band of the tile walk
     int remap;      // 1: XCD-aware block -> tile map
 };
@@ -65,7 +69,20 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                                            int fr, int fq) {
     const int m_base = m0 + wm * MFR * 16 + fr;
     const int n_base = n0 + wn * 64 + fq * 4;
-    if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
+    if constexpr (EPI == EPI_PARTIAL) {
+        float* slab = p.slab + (size_t)(blockIdx.x / p.n_tiles) * p.M * p.N;
+#pragma unroll
+        for (int mf = 0; mf < MFR; ++mf) {
+            const int m = m_base + mf * 16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = n_base + nf * 16;
+                if (n >= p.N) continue;
+                *(f32x4*)(slab + (size_t)m * p.N + n) = acc[mf][nf];
+            }
+        }
+    } else if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
 #pragma unroll
         for (int mf = 0; mf < MFR; ++mf) {
             const int m = m_base + mf * 16;
@@ -167,7 +184,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
     const int wm = wave >> 2, wn = wave & 3;
 
     int tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+    tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+    const int nk = p.K / BK / p.splits;                         // K tiles of this workgroup's range
+    const size_t k_first = (size_t)(blockIdx.x / p.n_tiles) * nk * BK;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane DMA source addresses (row clamped into the matrix; chunk pre-swizzled) ----
@@ -178,14 +197,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
         const int row = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const int grow = min(m0 + row, p.M - 1);
-        a_src[i] = p.A + (size_t)grow * p.lda + chunk * 8;
+        a_src[i] = p.A + (size_t)grow * p.lda + k_first + chunk * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int row = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const int grow = min(n0 + row, p.N - 1);
-        b_src[i] = p.W + (size_t)grow * p.K + chunk * 8;
+        b_src[i] = p.W + (size_t)grow * p.K + k_first + chunk * 8;
     }
 
     auto stage = [&](int s, int kt) {
@@ -207,7 +226,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
     const int a_row_off = (wm * MFR * 16 + fr) * ROW_BYTES;
     const int b_row_off = (wn * 64 + fr) * ROW_BYTES;
 
-    const int nk = p.K / BK;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();  // stage kt has landed (vmcnt(0) + barrier); everyone is done with the other stage
@@ -271,7 +289,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     const bool two_a = (wave + 8) < A_GROUPS;   // this wave moves a second A piece per region (wave-uniform)
 
     int tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+    tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+    const int nk = p.K / BK / p.splits;                         // K tiles of this workgroup's range
+    const size_t k_first = (size_t)(blockIdx.x / p.n_tiles) * nk * BK;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources: region-local row rho -> tile row; chunk pre-swizzled by the local row ----
@@ -286,18 +306,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
                 const int rho = g * 8 + (lane >> 3);
                 const int trow = (rho / (MFR * 8)) * (MFR * 16) + h * (MFR * 8) + rho % (MFR * 8);
                 const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-                a_src[h][u] = p.A + (size_t)min(m0 + trow, p.M - 1) * p.lda + chunk * 8;
+                a_src[h][u] = p.A + (size_t)min(m0 + trow, p.M - 1) * p.lda + k_first + chunk * 8;
             }
             {
                 const int g = wave + 8 * u;
                 const int rho = g * 8 + (lane >> 3);
                 const int tcol = (rho >> 5) * 64 + h * 32 + (rho & 31);
                 const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-                b_src[h][u] = p.W + (size_t)min(n0 + tcol, p.N - 1) * p.K + chunk * 8;
+                b_src[h][u] = p.W + (size_t)min(n0 + tcol, p.N - 1) * p.K + k_first + chunk * 8;
             }
         }
 
-    const int nk = p.K / BK;
     auto issue_a = [&](int h, int tt) {
         const int ks = min(tt, nk - 1) * BK;
         unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES;
@@ -423,13 +442,129 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq);
 }
 
+// Second pass of a split-K GEMM: adds the float32 partial tiles in split order (deterministic) and
+// applies the epilogue exactly as store_tile does.  One thread per 4 consecutive columns (PLAIN,
+// RESIDUAL) or per rotary / SwiGLU partner pair of 4-column groups (columns n and n + 16).
+template <int EPI>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) {
+    constexpr bool PAIRED = (EPI == LLADA_EPI_ROPE_QKV || EPI == LLADA_EPI_SWIGLU);
+    const int per_row = PAIRED ? p.N / 8 : p.N / 4;
+    const int64_t total = (int64_t)p.M * per_row;
+    const size_t slab_stride = (size_t)p.M * p.N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / per_row), c = (int)(i % per_row);
+        const int n1 = PAIRED ? (c >> 2) * 32 + (c & 3) * 4 : c * 4;
+        const float* src = p.slab + (size_t)m * p.N + n1;
+        f32x4 v1 = *(const f32x4*)src, v2 = {0.f, 0.f, 0.f, 0.f};
+        if (PAIRED) v2 = *(const f32x4*)(src + 16);
+        for (int sidx = 1; sidx < p.splits; ++sidx) {
+            const f32x4 t1 = *(const f32x4*)(src + sidx * slab_stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v1[e] += t1[e];
+            if (PAIRED) {
+                const f32x4 t2 = *(const f32x4*)(src + sidx * slab_stride + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v2[e] += t2[e];
+            }
+        }
+        u32x2 w1, w2;
+        if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
+            if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+                const u32x2 r = *(const u32x2*)(p.R + (size_t)m * p.ldr + n1);
+                v1[0] = bf16_to_f32(r[0] & 0xFFFF) + round_bf16(v1[0]);
+                v1[1] = bf16_to_f32(r[0] >> 16) + round_bf16(v1[1]);
+                v1[2] = bf16_to_f32(r[1] & 0xFFFF) + round_bf16(v1[2]);
+                v1[3] = bf16_to_f32(r[1] >> 16) + round_bf16(v1[3]);
+            }
+            w1[0] = pack_bf16x2(v1[0], v1[1]);
+            w1[1] = pack_bf16x2(v1[2], v1[3]);
+            *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
+        } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
+            f32x4 o1 = v1, o2 = v2;
+            if (n1 < p.rope_cols) {
+                const int ch = n1 & 127;                       // column inside the packed head
+                const int j = (ch >> 5) * 16 + (ch & 15);      // rotary frequency of element 0
+                const int pos = m % p.seq_len;
+                const f32x4 cs = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
+                const f32x4 sn = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = round_bf16(v1[e]), b = round_bf16(v2[e]);
+                    o1[e] = a * cs[e] - b * sn[e];
+                    o2[e] = b * cs[e] + a * sn[e];
+                }
+            }
+            w1[0] = pack_bf16x2(o1[0], o1[1]);
+            w1[1] = pack_bf16x2(o1[2], o1[3]);
+            w2[0] = pack_bf16x2(o2[0], o2[1]);
+            w2[1] = pack_bf16x2(o2[2], o2[3]);
+            *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
+            *(u32x2*)(p.C + (size_t)m * p.ldc + n1 + 16) = w2;
+        } else {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gb = round_bf16(v1[e]);
+                const float act = round_bf16(gb / (1.0f + __expf(-gb)));
+                o[e] = act * round_bf16(v2[e]);
+            }
+            w1[0] = pack_bf16x2(o[0], o[1]);
+            w1[1] = pack_bf16x2(o[2], o[3]);
+            *(u32x2*)(p.C + (size_t)m * p.ldc + (n1 >> 5) * 16 + (n1 & 15)) = w1;
+        }
+    }
+}
+
 int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel
 int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
+int g_force_splits = 0;   // test hook: > 0 forces the split count when a workspace is given
+size_t g_slab_bytes = 0;  // capacity of the caller's split-K workspace for the current call
+
+// Split count for a launch that would leave CUs idle: estimated time = rounds * (fill/drain +
+// K steps) + the reduce pass, in microseconds at ~1.25 us per K step.
+int pick_splits(int nt, int nk_total, int64_t M, int N, bool pipelined_ok) {
+    if (g_slab_bytes == 0) return 1;
+    auto fits = [&](int S) { return (size_t)S * M * N * 4 <= g_slab_bytes; };
+    if (g_force_splits > 0) return (nk_total % g_force_splits == 0 && fits(g_force_splits)) ? g_force_splits : 1;
+    if (nt >= 192) return 1;
+    int best = 1;
+    double best_cost = ((nt + 255) / 256) * (8.0 + 1.25 * nk_total);
+    for (int S = 2; S <= 16; ++S) {
+        if (nk_total % S) continue;
+        const int nk = nk_total / S;
+        if (nk < 4 || (pipelined_ok && (nk & 1))) continue;
+        if (!fits(S)) break;
+        const double cost = ((nt * S + 255) / 256) * (8.0 + 1.25 * nk) + 4.0 + (double)S * M * N * 4 / 3.0e6;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = S;
+        }
+    }
+    return best;
+}
 
 template <int MFR, int EPI>
-int launch(const GemmParams& p, hipStream_t stream) {
+int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     constexpr int BM = MFR * 32;
     constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
+    const int nk = q.K / BK / q.splits;
+    if constexpr (MFR != 8) {  // the 256-row tile does not fit the pipelined kernel's register budget
+        if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) {
+                    llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+                    return LLADA_ERR_HIP;
+                }
+                attr2_set = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
+            LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
+            return LLADA_OK;
+        }
+    }
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MFR, EPI>,
@@ -440,32 +575,28 @@ int launch(const GemmParams& p, hipStream_t stream) {
         }
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
+    LLADA_CHECK_LAUNCH("gemm_bf16_kernel");
+    return LLADA_OK;
+}
+
+template <int MFR, int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    constexpr int BM = MFR * 32;
     GemmParams q = p;
     q.band_m = g_band_m;
     q.remap = g_remap;
     q.tiles_m = (int)((p.M + BM - 1) / BM);
     q.tiles_n = (p.N + BN - 1) / BN;
-    const int nt = q.tiles_m * q.tiles_n;
-    const int nk = p.K / BK;
-    if constexpr (MFR != 8) {  // the 256-row tile does not fit the pipelined kernel's register budget
-      if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) {
-                llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
-                return LLADA_ERR_HIP;
-            }
-            attr2_set = true;
-        }
-        hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI>), dim3(nt), dim3(NTHREADS), lds, stream, q);
-        LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
-        return LLADA_OK;
-      }
-    }
-    hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(nt), dim3(NTHREADS), lds, stream, q);
-    LLADA_CHECK_LAUNCH("gemm_bf16_kernel");
+    q.n_tiles = q.tiles_m * q.tiles_n;
+    q.splits = pick_splits(q.n_tiles, p.K / BK, p.M, p.N, MFR != 8 && g_use_pipelined);
+    if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
+    const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
+    if (rc != LLADA_OK) return rc;
+    const int64_t items = (int64_t)p.M * p.N / 4;
+    const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(grid), dim3(256), 0, stream, q);
+    LLADA_CHECK_LAUNCH("splitk_reduce_kernel");
     return LLADA_OK;
 }
 
@@ -508,6 +639,7 @@ int dispatch_mfr(const GemmParams& p, int mfr, hipStream_t stream) {
 static int g_force_mfr = 0;
 extern "C" void llada_gemm_force_tile_rows(int rows) { g_force_mfr = rows / 32; }
 extern "C" void llada_gemm_use_pipelined(int on) { g_use_pipelined = on; }
+extern "C" void llada_gemm_force_splits(int splits) { g_force_splits = splits; }
 extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
     g_band_m = band_m > 0 ? band_m : 8;
     g_remap = remap;
@@ -569,7 +701,8 @@ static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, 
 
 extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int32_t N, int32_t K, int32_t lda,
                                int32_t ldc, int32_t epilogue, const void* aux, int32_t ldr, const float* rope_cos,
-                               const float* rope_sin, int32_t seq_len, void* stream) {
+                               const float* rope_sin, int32_t seq_len, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     LLADA_CHECK_ARG(A && W && C, "gemm: null operand");
     LLADA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     LLADA_CHECK_SUPPORTED(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
@@ -591,6 +724,9 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     p.ldc = ldc;
     p.ldr = ldr;
     p.seq_len = seq_len;
+    p.slab = (float*)workspace;
+    p.splits = 1;
+    g_slab_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
     const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N);
     LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
@@ -623,4 +759,15 @@ static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, 
             llada_set_error("gemm: unknown epilogue %d", epilogue);
             return LLADA_ERR_INVALID;
     }
+}
+
+// Bytes of split-K scratch that lets llada_gemm_bf16 use every CU for this shape (0 if the
+// shape already fills the chip).  Any smaller workspace (or none) is valid and only limits the
+// split count.
+extern "C" size_t llada_gemm_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int mfr = pick_mfr(M, N);
+    const int64_t nt = ((M + mfr * 32 - 1) / (mfr * 32)) * ((N + BN - 1) / BN);
+    if (nt >= 192) return 0;
+    return (size_t)16 * M * N * 4;
 }

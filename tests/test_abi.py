@@ -35,10 +35,10 @@ def test_struct_layouts_match_header():
 
 
 def test_argument_errors_without_gpu(lib):
-    assert lib.llada_gemm_bf16(None, None, None, 1, 8, 64, 64, 8, 0, None, 0, None, None, 0, None) == _lib.ERR_INVALID
+    assert lib.llada_gemm_bf16(None, None, None, 1, 8, 64, 64, 8, 0, None, 0, None, None, 0, None, 0, None) == _lib.ERR_INVALID
     assert b"null" in lib.llada_last_error()
     one = C.c_void_p(16)
-    assert lib.llada_gemm_bf16(one, one, one, 4, 8, 100, 104, 8, 0, None, 0, None, None, 0, None) == _lib.ERR_UNSUPPORTED
+    assert lib.llada_gemm_bf16(one, one, one, 4, 8, 100, 104, 8, 0, None, 0, None, None, 0, None, 0, None) == _lib.ERR_UNSUPPORTED
     args = _lib.RemaskArgs()
     assert lib.llada_remask_scores(C.byref(args), None) == _lib.ERR_INVALID
     assert lib.llada_forward_workspace_bytes(None, 1, 1, 1) == 0
@@ -50,7 +50,7 @@ def test_argument_errors_without_gpu(lib):
 
 def test_check_maps_status_to_reference_exceptions(lib):
     import pytest
-    lib.llada_gemm_bf16(None, None, None, 1, 8, 64, 64, 8, 0, None, 0, None, None, 0, None)
+    lib.llada_gemm_bf16(None, None, None, 1, 8, 64, 64, 8, 0, None, 0, None, None, 0, None, 0, None)
     with pytest.raises(AssertionError):
         _lib.check(_lib.ERR_INVALID)
     with pytest.raises(NotImplementedError):

@@ -34,14 +34,15 @@ def check(lib, rc):
     assert rc == 0, lib.llada_last_error().decode()
 
 
-def gemm(lib, A, W, epi=0, R=None, cos=None, sin=None, seq_len=0, out_cols=None):
+def gemm(lib, A, W, epi=0, R=None, cos=None, sin=None, seq_len=0, out_cols=None, workspace=None):
     M, K = A.shape
     N = W.shape[0]
     out = torch.full((M, out_cols or N), float("nan"), dtype=torch.bfloat16, device="cuda")
     rc = lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, K, out.shape[1], epi,
                              None if R is None else R.data_ptr(), 0 if R is None else R.shape[1],
                              None if cos is None else cos.data_ptr(), None if sin is None else sin.data_ptr(),
-                             seq_len, stream())
+                             seq_len, None if workspace is None else workspace.data_ptr(),
+                             0 if workspace is None else workspace.numel() * workspace.element_size(), stream())
     check(lib, rc)
     torch.cuda.synchronize()
     return out
@@ -74,7 +75,6 @@ def test_gemm_pipelined_equals_simple(lib, tile_rows):
     g = np.random.Generator(np.random.PCG64(21))
     A = bf(round_bf16(g.standard_normal((M, K), dtype=np.float32)))
     W = bf(round_bf16(g.standard_normal((N, K), dtype=np.float32) * 0.05))
-    lib.llada_gemm_use_pipelined.argtypes = [C.c_int]
     lib.llada_gemm_force_tile_rows(tile_rows)
     try:
         fast = gemm(lib, A, W)
@@ -84,6 +84,70 @@ def test_gemm_pipelined_equals_simple(lib, tile_rows):
         lib.llada_gemm_use_pipelined(1)
         lib.llada_gemm_force_tile_rows(0)
     assert torch.equal(fast, slow)
+
+
+@pytest.mark.parametrize("splits", [2, 4, 8])
+@pytest.mark.parametrize("tile_rows", [128, 192, 256])
+def test_gemm_splitk_exact_integers(lib, splits, tile_rows):
+    """Split-K (float32 partial tiles + ordered reduce) for every epilogue: exact on integers."""
+    M, N, K = 300, 768, 1024
+    g = np.random.Generator(np.random.PCG64(31))
+    A = g.integers(-3, 4, size=(M, K)).astype(np.float32)
+    W = g.integers(-3, 4, size=(N, K)).astype(np.float32)
+    R = round_bf16(g.standard_normal((M, N), dtype=np.float32) * 10)
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device="cuda")
+    lib.llada_gemm_force_tile_rows(tile_rows)
+    lib.llada_gemm_force_splits(splits)
+    try:
+        out = host(gemm(lib, bf(A), bf(W), workspace=ws))
+        res = host(gemm(lib, bf(A), bf(W), epi=1, R=bf(R), workspace=ws))
+    finally:
+        lib.llada_gemm_force_splits(0)
+        lib.llada_gemm_force_tile_rows(0)
+    assert np.array_equal(out, round_bf16(A @ W.T))
+    assert np.array_equal(res, round_bf16(R + round_bf16(A @ W.T)))
+
+
+def test_gemm_splitk_fused_epilogues(lib):
+    """Split-K + RoPE / SwiGLU second pass == the single-pass fused epilogues (integer operands make
+    the accumulation order irrelevant, so the comparison is bit-exact)."""
+    from llada_amd.weights import pack_gate_up, pack_qkv
+    n_seq, L, H = 2, 50, 2
+    d, F = H * 128, 384
+    M = n_seq * L
+    g = np.random.Generator(np.random.PCG64(32))
+    A = bf(g.integers(-2, 3, size=(M, d)).astype(np.float32))
+    Wq, Wk, Wv = (bf(g.integers(-2, 3, size=(d, d)).astype(np.float32)) for _ in range(3))
+    Wg, Wu = (bf(g.integers(-2, 3, size=(F, d)).astype(np.float32) * 0.125) for _ in range(2))
+    cos, sin = omodel.rope_tables(L, 128, 500000.0)
+    ct, st = dev(cos), dev(sin)
+    qkv_w, gu_w = pack_qkv(Wq, Wk, Wv, H), pack_gate_up(Wg, Wu)
+    ws = torch.empty(4 * M * 3 * d, dtype=torch.float32, device="cuda")
+    one_q = gemm(lib, A, qkv_w, epi=2, cos=ct, sin=st, seq_len=L)
+    one_g = gemm(lib, A, gu_w, epi=3, out_cols=F)
+    lib.llada_gemm_force_splits(2)
+    try:
+        two_q = gemm(lib, A, qkv_w, epi=2, cos=ct, sin=st, seq_len=L, workspace=ws)
+        two_g = gemm(lib, A, gu_w, epi=3, out_cols=F, workspace=ws)
+    finally:
+        lib.llada_gemm_force_splits(0)
+    assert torch.equal(one_q, two_q)
+    assert torch.equal(one_g, two_g)
+
+
+def test_gemm_splitk_auto_small_m(lib):
+    """M = 384 (one sequence): the library splits K on its own when given a workspace; results stay
+    within accumulation-order noise of the unsplit run."""
+    M, N, K = 384, 4096, 4096
+    g = np.random.Generator(np.random.PCG64(33))
+    A = bf(round_bf16(g.standard_normal((M, K), dtype=np.float32)))
+    W = bf(round_bf16(g.standard_normal((N, K), dtype=np.float32) * 0.02))
+    need = lib.llada_gemm_workspace_bytes(M, N, K)
+    assert need > 0 and lib.llada_gemm_workspace_bytes(3072, N, K) == 0
+    ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+    a = host(gemm(lib, A, W))
+    b = host(gemm(lib, A, W, workspace=ws))
+    assert ulp_distance(a, b).max() <= 1 or np.abs(a - b).max() <= 2e-2
 
 
 @pytest.mark.parametrize("shape", [(512, 512, 256), (3072, 1024, 4096), (130, 768, 1024)])
@@ -111,7 +175,7 @@ def test_gemm_residual(lib):
     # in place (C aliases R), as the forward uses it
     At, Wt = bf(A), bf(W)
     rc = lib.llada_gemm_bf16(At.data_ptr(), Wt.data_ptr(), Rt.data_ptr(), M, N, K, K, N, 1, Rt.data_ptr(), N,
-                             None, None, 0, stream())
+                             None, None, 0, None, 0, stream())
     check(lib, rc)
     torch.cuda.synchronize()
     assert np.array_equal(host(Rt), ref)
@@ -162,7 +226,8 @@ def test_gemm_swiglu_epilogue(lib):
 
 def test_gemm_rejects_bad_shapes(lib):
     a = torch.zeros(8, 96, dtype=torch.bfloat16, device="cuda")
-    rc = lib.llada_gemm_bf16(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 96, 96, 8, 0, None, 0, None, None, 0, None)
+    rc = lib.llada_gemm_bf16(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 96, 96, 8, 0, None, 0, None, None, 0, None, 0,
+                             None)
     assert rc == -2 and b"K=" in lib.llada_last_error()
 
 

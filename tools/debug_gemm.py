@@ -20,7 +20,7 @@ else:
 At = torch.from_numpy(A).cuda().to(torch.bfloat16); Wt = torch.from_numpy(W).cuda().to(torch.bfloat16)
 out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
 lib.llada_gemm_force_tile_rows(rows)
-rc = lib.llada_gemm_bf16(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, K, N, 0, None, 0, None, None, 0, None)
+rc = lib.llada_gemm_bf16(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, K, N, 0, None, 0, None, None, 0, None, 0, None)
 torch.cuda.synchronize()
 assert rc == 0, lib.llada_last_error()
 o = out.float().cpu().numpy(); ref = A @ W.T

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, ".")
 from llada_amd import _lib
 lib = _lib.load()
-lib.llada_gemm_use_pipelined.argtypes = [C.c_int]
+pass
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["p192", "s192", "p128", "s256"]
@@ -26,13 +26,13 @@ for name, (N, K, epi) in shapes.items():
             lib.llada_gemm_use_pipelined(1 if v[0] == "p" else 0)
             lib.llada_gemm_force_tile_rows(int(v[1:]))
             for _ in range(3):
-                lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, epi, None, 0, None, None, 0, None)
+                lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, epi, None, 0, None, None, 0, None, 0, None)
             torch.cuda.synchronize()
             n = 20
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n):
-                lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, epi, None, 0, None, None, 0, None)
+                lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, epi, None, 0, None, None, 0, None, 0, None)
             e1.record(); torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / n)
     print(name, M, N, K, " ".join(f"{v}: {np.median(t)*1e3:7.1f}us {flops/np.median(t)/1e9:7.1f}TF" for v, t in times.items()), flush=True)

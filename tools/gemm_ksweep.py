@@ -1,7 +1,7 @@
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from llada_amd import _lib
-lib = _lib.load(); lib.llada_gemm_use_pipelined.argtypes = [C.c_int]
+lib = _lib.load(); pass
 M = 3072; N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for pipe in (1, 0):
     lib.llada_gemm_use_pipelined(pipe); lib.llada_gemm_force_tile_rows(192)
@@ -10,10 +10,10 @@ for pipe in (1, 0):
         Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ts = []
         for r in range(5):
-            for _ in range(3): lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, 0, None, 0, None, None, 0, None)
+            for _ in range(3): lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, 0, None, 0, None, None, 0, None, 0, None)
             torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); n = 20
             e0.record()
-            for _ in range(n): lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, 0, None, 0, None, None, 0, None)
+            for _ in range(n): lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, K, N, 0, None, 0, None, None, 0, None, 0, None)
             e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / n * 1e3)
         t = np.median(ts); print(f"pipe={pipe} N={N} K={K:6d} {t:8.1f} us  {2.0*M*N*K/t/1e6:8.1f} TF  per-kstep {t/(K/64)*1e3:7.1f} ns", flush=True)
