@@ -37,6 +37,7 @@ struct GemmParams {
     float* slab;    // split-K partial sums [splits][M][N] float32, or nullptr
     int splits;     // K is cut into `splits` equal ranges, one workgroup each per output tile
     int n_tiles;    // tiles_m * tiles_n
+    int no_store;   // diagnostic: skip the epilogue stores (timing experiments only)
     int band_m;     // M tiles per band of the tile walk
     int remap;      // 1: XCD-aware block -> tile map
 };
@@ -63,13 +64,21 @@ __device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int 
     tn = in_band / rows;
 }
 
-// Epilogue shared by both main loops: the lane holds C[m][n .. n+3] for m = row(mf), n = col(nf).
+// Epilogue shared by both main loops.  After the MFMAs a lane holds C[m][n .. n+3] for 4*MFR
+// (row, column-group) pairs, i.e. 8-byte pieces scattered over 16 rows per fragment; stored like
+// that every wave instruction touches 16 rows x 32 B and the tile's write-out costs ~10 us.  So the
+// results (after the fused rotary / SwiGLU arithmetic, rounded to bf16) go through the wave's own
+// slice of the now idle staging LDS (row stride = row bytes + 16, conflict-free for the 8-byte
+// writes) and leave as 16 bytes per lane, 8 lanes per 128-byte row: whole cache lines.  The
+// residual is read with the same full-line pattern during the write-out.
+// The caller guarantees that no DMA or LDS read of the main loop is outstanding (barrier).
 template <int MFR, int EPI>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR][4], int m0, int n0, int wm, int wn,
-                                           int fr, int fq) {
-    const int m_base = m0 + wm * MFR * 16 + fr;
-    const int n_base = n0 + wn * 64 + fq * 4;
+                                           int fr, int fq, unsigned char* smem, int wave, int lane) {
+    if (p.no_store) return;
     if constexpr (EPI == EPI_PARTIAL) {
+        const int m_base = m0 + wm * MFR * 16 + fr;
+        const int n_base = n0 + wn * 64 + fq * 4;
         float* slab = p.slab + (size_t)(blockIdx.x / p.n_tiles) * p.M * p.N;
 #pragma unroll
         for (int mf = 0; mf < MFR; ++mf) {
@@ -82,87 +91,98 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                 *(f32x4*)(slab + (size_t)m * p.N + n) = acc[mf][nf];
             }
         }
-    } else if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
+    } else {
+        constexpr bool SWI = (EPI == LLADA_EPI_SWIGLU);
+        constexpr int OUTC = SWI ? 32 : 64;            // output columns of this wave
+        constexpr int ROWB = OUTC * 2 + 16;            // LDS row stride in bytes
+        constexpr int MG = (MFR == 8) ? 4 : MFR;       // m fragments per pass (LDS budget)
+        constexpr int LPR = OUTC * 2 / 16;             // lanes per output row in the write-out
+        constexpr int RPI = 64 / LPR;                  // rows per write-out instruction
+        unsigned char* my = smem + wave * (MG * 16 * ROWB);
+        const int out_n0 = SWI ? (n0 + wn * 64) / 2 : n0 + wn * 64;   // first output column of the wave
+        const int out_cols = SWI ? p.N / 2 : p.N;
+        [[maybe_unused]] const bool rope = n0 < p.rope_cols;          // uniform per tile (rope_cols % 256 == 0)
 #pragma unroll
-        for (int mf = 0; mf < MFR; ++mf) {
-            const int m = m_base + mf * 16;
-            if (m >= p.M) continue;
+        for (int pass = 0; pass < MFR / MG; ++pass) {
+            // ---- registers -> LDS (bf16) ----
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const int n = n_base + nf * 16;
-                if (n >= p.N) continue;
-                f32x4 v = acc[mf][nf];
-                if constexpr (EPI == LLADA_EPI_RESIDUAL) {
-                    const u32x2 r = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
-                    v[0] = bf16_to_f32(r[0] & 0xFFFF) + round_bf16(v[0]);
-                    v[1] = bf16_to_f32(r[0] >> 16) + round_bf16(v[1]);
-                    v[2] = bf16_to_f32(r[1] & 0xFFFF) + round_bf16(v[2]);
-                    v[3] = bf16_to_f32(r[1] >> 16) + round_bf16(v[3]);
-                }
-                u32x2 o;
-                o[0] = pack_bf16x2(v[0], v[1]);
-                o[1] = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
-            }
-        }
-    } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
-        // packed head layout: 16-column blocks 0-15 | 64-79 | 16-31 | 80-95 | ...; this wave holds
-        // blocks (nf, nf+1) = rotary pairs.  Columns >= rope_cols (the V third) are stored as is.
-        const bool rope = n0 < p.rope_cols;  // uniform per tile: rope_cols % 256 == 0
+            for (int ml = 0; ml < MG; ++ml) {
+                const int mf = pass * MG + ml;
+                unsigned char* row = my + (ml * 16 + fr) * ROWB + fq * 8;
+                if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
 #pragma unroll
-        for (int mf = 0; mf < MFR; ++mf) {
-            const int m = m_base + mf * 16;
-            if (m >= p.M) continue;
-            const int pos = m % p.seq_len;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                f32x4 x1 = acc[mf][2 * pr], x2 = acc[mf][2 * pr + 1];
-                f32x4 o1, o2;
-                if (rope) {
-                    const int j = (wn & 1) * 32 + pr * 16 + fq * 4;  // rotary frequency index of reg 0
-                    const f32x4 c = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
-                    const f32x4 s = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = round_bf16(x1[e]), b = round_bf16(x2[e]);
-                        o1[e] = a * c[e] - b * s[e];
-                        o2[e] = b * c[e] + a * s[e];
+                    for (int nf = 0; nf < 4; ++nf) {
+                        u32x2 o;
+                        o[0] = pack_bf16x2(acc[mf][nf][0], acc[mf][nf][1]);
+                        o[1] = pack_bf16x2(acc[mf][nf][2], acc[mf][nf][3]);
+                        *(u32x2*)(row + nf * 32) = o;
                     }
-                } else {
-                    o1 = x1;
-                    o2 = x2;
+                } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
+                    // packed head layout: 16-column blocks 0-15 | 64-79 | 16-31 | 80-95 | ...: fragments
+                    // (2pr, 2pr+1) are rotary partners.  Columns >= rope_cols (V) pass through.
+                    const int m = m0 + wm * MFR * 16 + mf * 16 + fr;
+                    const int pos = min(m, p.M - 1) % p.seq_len;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const f32x4 x1 = acc[mf][2 * pr], x2 = acc[mf][2 * pr + 1];
+                        f32x4 o1 = x1, o2 = x2;
+                        if (rope) {
+                            const int j = (wn & 1) * 32 + pr * 16 + fq * 4;  // rotary frequency of element 0
+                            const f32x4 c = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
+                            const f32x4 sn = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = round_bf16(x1[e]), b = round_bf16(x2[e]);
+                                o1[e] = a * c[e] - b * sn[e];
+                                o2[e] = b * c[e] + a * sn[e];
+                            }
+                        }
+                        u32x2 w1, w2;
+                        w1[0] = pack_bf16x2(o1[0], o1[1]);
+                        w1[1] = pack_bf16x2(o1[2], o1[3]);
+                        w2[0] = pack_bf16x2(o2[0], o2[1]);
+                        w2[1] = pack_bf16x2(o2[2], o2[3]);
+                        *(u32x2*)(row + (2 * pr) * 32) = w1;
+                        *(u32x2*)(row + (2 * pr + 1) * 32) = w2;
+                    }
+                } else {  // SWIGLU: fragments (2pr, 2pr+1) = (gate, up) of the same 16 hidden units
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const f32x4 g = acc[mf][2 * pr], u = acc[mf][2 * pr + 1];
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gb = round_bf16(g[e]);
+                            const float act = round_bf16(gb / (1.0f + __expf(-gb)));
+                            o[e] = act * round_bf16(u[e]);
+                        }
+                        u32x2 w;
+                        w[0] = pack_bf16x2(o[0], o[1]);
+                        w[1] = pack_bf16x2(o[2], o[3]);
+                        *(u32x2*)(row + pr * 32) = w;
+                    }
                 }
-                const int n1 = n_base + (2 * pr) * 16, n2 = n1 + 16;
-                u32x2 w1, w2;
-                w1[0] = pack_bf16x2(o1[0], o1[1]);
-                w1[1] = pack_bf16x2(o1[2], o1[3]);
-                w2[0] = pack_bf16x2(o2[0], o2[1]);
-                w2[1] = pack_bf16x2(o2[2], o2[3]);
-                *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
-                *(u32x2*)(p.C + (size_t)m * p.ldc + n2) = w2;
             }
-        }
-    } else {  // LLADA_EPI_SWIGLU: blocks (nf even, nf odd) = (gate, up) of the same 16 hidden units
-        const bool cols_in = n0 + wn * 64 < p.N;  // N % 64 == 0: a wave's 64 columns are all in or all out
+            // ---- LDS -> global, whole rows ----
+            const int r_in = lane / LPR, chunk = lane % LPR;
+            const int n = out_n0 + chunk * 8;
 #pragma unroll
-        for (int mf = 0; mf < MFR; ++mf) {
-            const int m = m_base + mf * 16;
-            if (m >= p.M || !cols_in) continue;
+            for (int i = 0; i < MG * 16 / RPI; ++i) {
+                const int rl = i * RPI + r_in;
+                const int m = m0 + wm * MFR * 16 + pass * MG * 16 + rl;
+                u32x4 v = *(const u32x4*)(my + rl * ROWB + chunk * 16);
+                if (m < p.M && n < out_cols) {
+                    if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+                        const u32x4 r = *(const u32x4*)(p.R + (size_t)m * p.ldr + n);
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const f32x4 g = acc[mf][2 * pr], u = acc[mf][2 * pr + 1];
-                const int f = (n0 + wn * 64) / 2 + pr * 16 + fq * 4;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gb = round_bf16(g[e]);
-                    const float act = round_bf16(gb / (1.0f + __expf(-gb)));
-                    o[e] = act * round_bf16(u[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = bf16_to_f32(r[e] & 0xFFFF) + bf16_to_f32(v[e] & 0xFFFF);
+                            const float hi = bf16_to_f32(r[e] >> 16) + bf16_to_f32(v[e] >> 16);
+                            v[e] = pack_bf16x2(lo, hi);
+                        }
+                    }
+                    *(u32x4*)(p.C + (size_t)m * p.ldc + n) = v;
                 }
-                u32x2 w;
-                w[0] = pack_bf16x2(o[0], o[1]);
-                w[1] = pack_bf16x2(o[2], o[3]);
-                *(u32x2*)(p.C + (size_t)m * p.ldc + f) = w;
             }
         }
     }
@@ -248,7 +268,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
         }
     }
 
-    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq);
+    __syncthreads();  // all waves are done reading the last stage: the LDS is free
+    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,7 +460,59 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
 #undef BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills must land before the LDS is released
 
-    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq);
+    __syncthreads();  // all waves are done reading the last stage: the LDS is free
+    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane);
+}
+
+// Elementwise epilogue on float32 sums, identical to store_tile's: v1 = columns n1..n1+3 of row m,
+// v2 = columns n1+16..n1+19 (the rotary / SwiGLU partners; unused otherwise).
+template <int EPI>
+__device__ __forceinline__ void finish_and_store(const GemmParams& p, int m, int n1, f32x4 v1, f32x4 v2) {
+    u32x2 w1, w2;
+    if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
+        if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+            const u32x2 r = *(const u32x2*)(p.R + (size_t)m * p.ldr + n1);
+            v1[0] = bf16_to_f32(r[0] & 0xFFFF) + round_bf16(v1[0]);
+            v1[1] = bf16_to_f32(r[0] >> 16) + round_bf16(v1[1]);
+            v1[2] = bf16_to_f32(r[1] & 0xFFFF) + round_bf16(v1[2]);
+            v1[3] = bf16_to_f32(r[1] >> 16) + round_bf16(v1[3]);
+        }
+        w1[0] = pack_bf16x2(v1[0], v1[1]);
+        w1[1] = pack_bf16x2(v1[2], v1[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
+    } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
+        f32x4 o1 = v1, o2 = v2;
+        if (n1 < p.rope_cols) {
+            const int ch = n1 & 127;                       // column inside the packed head
+            const int j = (ch >> 5) * 16 + (ch & 15);      // rotary frequency of element 0
+            const int pos = m % p.seq_len;
+            const f32x4 cs = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
+            const f32x4 sn = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = round_bf16(v1[e]), b = round_bf16(v2[e]);
+                o1[e] = a * cs[e] - b * sn[e];
+                o2[e] = b * cs[e] + a * sn[e];
+            }
+        }
+        w1[0] = pack_bf16x2(o1[0], o1[1]);
+        w1[1] = pack_bf16x2(o1[2], o1[3]);
+        w2[0] = pack_bf16x2(o2[0], o2[1]);
+        w2[1] = pack_bf16x2(o2[2], o2[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n1 + 16) = w2;
+    } else {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gb = round_bf16(v1[e]);
+            const float act = round_bf16(gb / (1.0f + __expf(-gb)));
+            o[e] = act * round_bf16(v2[e]);
+        }
+        w1[0] = pack_bf16x2(o[0], o[1]);
+        w1[1] = pack_bf16x2(o[2], o[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + (n1 >> 5) * 16 + (n1 & 15)) = w1;
+    }
 }
 
 // Second pass of a split-K GEMM: adds the float32 partial tiles in split order (deterministic) and
@@ -467,51 +540,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
                 for (int e = 0; e < 4; ++e) v2[e] += t2[e];
             }
         }
-        u32x2 w1, w2;
-        if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
-            if constexpr (EPI == LLADA_EPI_RESIDUAL) {
-                const u32x2 r = *(const u32x2*)(p.R + (size_t)m * p.ldr + n1);
-                v1[0] = bf16_to_f32(r[0] & 0xFFFF) + round_bf16(v1[0]);
-                v1[1] = bf16_to_f32(r[0] >> 16) + round_bf16(v1[1]);
-                v1[2] = bf16_to_f32(r[1] & 0xFFFF) + round_bf16(v1[2]);
-                v1[3] = bf16_to_f32(r[1] >> 16) + round_bf16(v1[3]);
-            }
-            w1[0] = pack_bf16x2(v1[0], v1[1]);
-            w1[1] = pack_bf16x2(v1[2], v1[3]);
-            *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
-        } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
-            f32x4 o1 = v1, o2 = v2;
-            if (n1 < p.rope_cols) {
-                const int ch = n1 & 127;                       // column inside the packed head
-                const int j = (ch >> 5) * 16 + (ch & 15);      // rotary frequency of element 0
-                const int pos = m % p.seq_len;
-                const f32x4 cs = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
-                const f32x4 sn = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = round_bf16(v1[e]), b = round_bf16(v2[e]);
-                    o1[e] = a * cs[e] - b * sn[e];
-                    o2[e] = b * cs[e] + a * sn[e];
-                }
-            }
-            w1[0] = pack_bf16x2(o1[0], o1[1]);
-            w1[1] = pack_bf16x2(o1[2], o1[3]);
-            w2[0] = pack_bf16x2(o2[0], o2[1]);
-            w2[1] = pack_bf16x2(o2[2], o2[3]);
-            *(u32x2*)(p.C + (size_t)m * p.ldc + n1) = w1;
-            *(u32x2*)(p.C + (size_t)m * p.ldc + n1 + 16) = w2;
-        } else {
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gb = round_bf16(v1[e]);
-                const float act = round_bf16(gb / (1.0f + __expf(-gb)));
-                o[e] = act * round_bf16(v2[e]);
-            }
-            w1[0] = pack_bf16x2(o[0], o[1]);
-            w1[1] = pack_bf16x2(o[2], o[3]);
-            *(u32x2*)(p.C + (size_t)m * p.ldc + (n1 >> 5) * 16 + (n1 & 15)) = w1;
-        }
+        finish_and_store<EPI>(p, m, n1, v1, v2);
     }
 }
 
@@ -580,16 +609,19 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     return LLADA_OK;
 }
 
+int g_no_store = 0;       // diagnostic hook
 template <int MFR, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = MFR * 32;
     GemmParams q = p;
     q.band_m = g_band_m;
     q.remap = g_remap;
+    q.no_store = g_no_store;
     q.tiles_m = (int)((p.M + BM - 1) / BM);
     q.tiles_n = (p.N + BN - 1) / BN;
     q.n_tiles = q.tiles_m * q.tiles_n;
-    q.splits = pick_splits(q.n_tiles, p.K / BK, p.M, p.N, MFR != 8 && g_use_pipelined);
+    const int nk_total = p.K / BK;
+    q.splits = pick_splits(q.n_tiles, nk_total, p.M, p.N, MFR != 8 && g_use_pipelined);
     if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
     const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
     if (rc != LLADA_OK) return rc;
@@ -600,9 +632,12 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return LLADA_OK;
 }
 
-// Pick the M tile (128 / 192 / 256 rows) that wastes the least work: padding rows plus the
-// idle CUs of the last, partially filled round of tiles over the 256 CUs.
-int pick_mfr(int64_t M, int N) {
+// Pick the M tile (128 / 192 / 256 rows) that wastes the least work: padded rows plus the idle
+// CUs of the last, partially filled round of tiles over the 256 CUs, times a per-tile efficiency
+// factor (the 192-row tile runs the pipelined loop at the best rate, 128 rows re-read more operand
+// bytes per flop, 256 rows only has the simple two-stage loop).
+int pick_mfr(int64_t M, int N, int K) {
+    (void)K;
     const int cands[3] = {8, 6, 4};
     int best = 8;
     double best_cost = 1e30;
@@ -612,9 +647,6 @@ int pick_mfr(int64_t M, int N) {
         const int64_t tiles_m = (M + bm - 1) / bm;
         const int64_t nt = tiles_m * tiles_n;
         const int64_t rounds = (nt + 255) / 256;
-        // time ~ rounds * (tile work) * a per-tile efficiency factor: the 192-row tile runs the
-        // pipelined main loop at the best rate, 128 rows re-read more operand bytes per flop, 256
-        // rows only has the simple two-stage loop
         const double cost = (double)rounds * bm * (c == 8 ? 1.10 : (c == 6 ? 1.0 : 1.08));
         if (cost < best_cost) {
             best_cost = cost;
@@ -640,6 +672,8 @@ static int g_force_mfr = 0;
 extern "C" void llada_gemm_force_tile_rows(int rows) { g_force_mfr = rows / 32; }
 extern "C" void llada_gemm_use_pipelined(int on) { g_use_pipelined = on; }
 extern "C" void llada_gemm_force_splits(int splits) { g_force_splits = splits; }
+extern "C" void llada_gemm_no_store(int on) { g_no_store = on; }
+
 extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
     g_band_m = band_m > 0 ? band_m : 8;
     g_remap = remap;
@@ -707,9 +741,10 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     LLADA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     LLADA_CHECK_SUPPORTED(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
     LLADA_CHECK_SUPPORTED(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
+    LLADA_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A and W must be 16-byte aligned");
     LLADA_CHECK_SUPPORTED(M < (1ll << 31), "gemm: M too large");
     LLADA_CHECK_ARG(lda >= K && (lda % 8) == 0, "gemm: lda=%d must be >= K and a multiple of 8", lda);
-    LLADA_CHECK_ARG((ldc % 4) == 0, "gemm: ldc=%d must be a multiple of 4", ldc);
+    LLADA_CHECK_ARG((ldc % 8) == 0 && ((uintptr_t)C & 15) == 0, "gemm: ldc=%d must be a multiple of 8 and C 16-byte aligned", ldc);
     GemmParams p{};
     p.A = (const bf16_t*)A;
     p.W = (const bf16_t*)W;
@@ -728,7 +763,7 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     p.splits = 1;
     g_slab_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
-    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N);
+    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
     LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
     const bool prof = g_prof.epilogue == epilogue && g_prof.count < g_prof.capacity;
     if (prof) (void)hipEventRecord(g_prof.start[g_prof.count], s);
@@ -744,7 +779,7 @@ static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, 
             LLADA_CHECK_ARG(ldc >= N, "gemm: ldc < N");
             return dispatch_mfr<LLADA_EPI_PLAIN>(p, mfr, s);
         case LLADA_EPI_RESIDUAL:
-            LLADA_CHECK_ARG(aux != nullptr && ldr >= N && (ldr % 4) == 0 && ldc >= N, "gemm: residual needs aux/ldr");
+            LLADA_CHECK_ARG(aux != nullptr && ldr >= N && (ldr % 8) == 0 && ((uintptr_t)aux & 15) == 0 && ldc >= N, "gemm: residual needs aux/ldr");
             return dispatch_mfr<LLADA_EPI_RESIDUAL>(p, mfr, s);
         case LLADA_EPI_ROPE_QKV:
             LLADA_CHECK_ARG(rope_cos && rope_sin && seq_len > 0 && ldc >= N, "gemm: rope epilogue needs tables and seq_len");
@@ -761,13 +796,13 @@ static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, 
     }
 }
 
-// Bytes of split-K scratch that lets llada_gemm_bf16 use every CU for this shape (0 if the
-// shape already fills the chip).  Any smaller workspace (or none) is valid and only limits the
-// split count.
+// Bytes of float32 scratch with which llada_gemm_bf16 can balance this shape over all CUs (0 if it
+// needs none).  Any smaller workspace (or none) is valid: the call then falls back to whole tiles
+// per workgroup.
 extern "C" size_t llada_gemm_workspace_bytes(int64_t M, int32_t N, int32_t K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int mfr = pick_mfr(M, N);
-    const int64_t nt = ((M + mfr * 32 - 1) / (mfr * 32)) * ((N + BN - 1) / BN);
-    if (nt >= 192) return 0;
-    return (size_t)16 * M * N * 4;
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
+    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
+    const int bm = mfr * 32;
+    const long long nt = ((M + bm - 1) / bm) * ((N + BN - 1) / BN);
+    return nt >= 192 ? 0 : (size_t)16 * M * N * 4;
 }

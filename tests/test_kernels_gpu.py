@@ -123,10 +123,10 @@ def test_gemm_splitk_fused_epilogues(lib):
     ct, st = dev(cos), dev(sin)
     qkv_w, gu_w = pack_qkv(Wq, Wk, Wv, H), pack_gate_up(Wg, Wu)
     ws = torch.empty(4 * M * 3 * d, dtype=torch.float32, device="cuda")
-    one_q = gemm(lib, A, qkv_w, epi=2, cos=ct, sin=st, seq_len=L)
-    one_g = gemm(lib, A, gu_w, epi=3, out_cols=F)
-    lib.llada_gemm_force_splits(2)
     try:
+        one_q = gemm(lib, A, qkv_w, epi=2, cos=ct, sin=st, seq_len=L)
+        one_g = gemm(lib, A, gu_w, epi=3, out_cols=F)
+        lib.llada_gemm_force_splits(2)
         two_q = gemm(lib, A, qkv_w, epi=2, cos=ct, sin=st, seq_len=L, workspace=ws)
         two_g = gemm(lib, A, gu_w, epi=3, out_cols=F, workspace=ws)
     finally:
