@@ -49,6 +49,25 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_uni
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_uniform, 16, 0, 0);
 }
 
+// The same for lanes 0-31 only (512 contiguous LDS bytes).  EXEC is all ones in these kernels; the
+// upper half is cleared around the one instruction and M0 is put back (the compiler tracks neither).
+// M0 needs one wait state before an LDS-DMA.
+__device__ __forceinline__ void glds16_lo32(const bf16_t* src, unsigned char* lds_uniform) {
+    const unsigned lds_off = (unsigned)(size_t)(lds_ptr_t)lds_uniform;
+    unsigned saved_m0;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 exec_hi, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved_m0)
+        : "v"(src), "s"(lds_off)
+        : "memory");
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
 // tiles, and walk the tiles in bands of 8 M-tiles so the 32 tiles resident on an XCD share
 // their A rows and W rows through that XCD's L2.  Bijective for any tile count.
@@ -307,7 +326,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const bool two_a = (wave + 8) < A_GROUPS;   // this wave moves a second A piece per region (wave-uniform)
+    // Every wave moves the same number of pieces per region, so the counted waits are compile-time
+    // constants and the loop has no branches (a wave-uniform "does this wave move a second piece"
+    // test costs 7-9 % of the kernel).  An A region of the 192-row tile is 12 KiB = 8 whole pieces
+    // plus 8 half pieces (4 rows, lanes 0-31 of a second instruction issued with EXEC[63:32] = 0).
+    constexpr bool two_a = A_GROUPS > 8;
+    constexpr bool half_a = A_GROUPS == 12;
 
     int tm, tn;
     tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
@@ -323,8 +347,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             {
-                const int g = min(wave + 8 * u, A_GROUPS - 1);
-                const int rho = g * 8 + (lane >> 3);
+                // second instruction: rows 64 + 4*wave .. +3 (half pieces) or piece wave + 8 (256-row tile)
+                const int rho = (u == 0) ? wave * 8 + (lane >> 3)
+                                         : (half_a ? 64 + wave * 4 + ((lane & 31) >> 3) : min(wave + 8, A_GROUPS - 1) * 8 + (lane >> 3));
                 const int trow = (rho / (MFR * 8)) * (MFR * 16) + h * (MFR * 8) + rho % (MFR * 8);
                 const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
                 a_src[h][u] = p.A + (size_t)min(m0 + trow, p.M - 1) * p.lda + k_first + chunk * 8;
@@ -342,7 +367,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         const int ks = min(tt, nk - 1) * BK;
         unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES;
         glds16(a_src[h][0] + ks, base + wave * 1024);
-        if (two_a) glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
+        if constexpr (half_a)
+            glds16_lo32(a_src[h][1] + ks, base + 8 * 1024 + wave * 512);
+        else if constexpr (two_a)
+            glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
     };
     auto issue_b = [&](int h, int tt) {
         const int ks = min(tt, nk - 1) * BK;
@@ -634,8 +662,8 @@ int launch(const GemmParams& p, hipStream_t stream) {
 
 // Pick the M tile (128 / 192 / 256 rows) that wastes the least work: padded rows plus the idle
 // CUs of the last, partially filled round of tiles over the 256 CUs, times a per-tile efficiency
-// factor (the 192-row tile runs the pipelined loop at the best rate, 128 rows re-read more operand
-// bytes per flop, 256 rows only has the simple two-stage loop).
+// factor (measured: the 128- and 192-row pipelined loops run at the same rate per row within a few
+// percent; 256 rows only has the simple two-stage loop).
 int pick_mfr(int64_t M, int N, int K) {
     (void)K;
     const int cands[3] = {8, 6, 4};
@@ -647,7 +675,7 @@ int pick_mfr(int64_t M, int N, int K) {
         const int64_t tiles_m = (M + bm - 1) / bm;
         const int64_t nt = tiles_m * tiles_n;
         const int64_t rounds = (nt + 255) / 256;
-        const double cost = (double)rounds * bm * (c == 8 ? 1.10 : (c == 6 ? 1.0 : 1.08));
+        const double cost = (double)rounds * bm * (c == 8 ? 1.10 : (c == 6 ? 1.0 : 1.02));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
