@@ -121,7 +121,7 @@ def main():
         state["n"] += 1
         if state["n"] == W_:
             sync_all()
-            lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers)
+            lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L)
             state["t0"] = time.perf_counter()
         elif state["n"] == W_ + K_:
             sync_all()
@@ -129,7 +129,7 @@ def main():
 
     if W_ == 0:
         sync_all()
-        lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers)
+        lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L)
         state["t0"] = time.perf_counter()
     out = None
     while state["t1"] is None:
@@ -152,8 +152,11 @@ def main():
         gemm_flops = 2.0 * M * (2 * F) * d
         gemm_ms = tot_ms.value / max(n_s.value, 1)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        lin = cfg.n_layers * (4 * d * d + 3 * d * F)
-        flops_step = 2.0 * M * lin + 2.0 * (B * bl) * d * V + M * 4.0 * L * d * cfg.n_layers
+        # executed FLOPs of one step: all rows through every layer, except that the last layer's
+        # output projection and MLP (and the LM head) only see the B*bl block rows
+        R = B * bl
+        lin = cfg.n_layers * (4 * d * d + 3 * d * F) - (d * d + 3 * d * F)
+        flops_step = 2.0 * M * lin + 2.0 * R * (d * d + 3 * d * F) + 2.0 * R * d * V + M * 4.0 * L * d * cfg.n_layers
         rec = {
             "metric": "generated tokens/sec/node, LLaDA-8B gen256 steps256 blk32; ms/denoise step",
             "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": K_, "warmup": W_,

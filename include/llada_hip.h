@@ -115,6 +115,12 @@ int llada_forward(const llada_config* cfg, const llada_weights* w, const int64_t
 int llada_embed_bf16(const void* wte, const int64_t* ids, void* out, int64_t n_tokens, int32_t d, int64_t vocab,
                      void* stream);
 
+/* out[r, :] = in[rows[r], :], in [n_in, d] bf16.  The forward uses it in the last layer, where only the
+ * rows whose logits are wanted (generate.py:125-128 discards the rest; get_log_likelihood.py:40
+ * indexes the masked answer positions) go through the output projection and the MLP. */
+int llada_gather_rows_bf16(const void* in, const int32_t* rows, void* out, int64_t n_rows, int32_t d, int64_t n_in,
+                           void* stream);
+
 /* RMSNorm: out[r, :] = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w), float32 inside; if row_index
  * is not NULL, output row r reads input row row_index[r] (gather fused into the final norm). */
 int llada_rmsnorm_bf16(const void* x, const void* w, void* out, int64_t n_rows, int32_t d, float eps,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "llada_forward": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32, vp,
                                 C.c_int32, vp, vp, C.c_size_t, vp]),
     "llada_embed_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
+    "llada_gather_rows_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp, vp]),
     "llada_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
                                   C.c_int32, vp, vp, C.c_int32, vp, C.c_size_t, vp]),
@@ -68,7 +69,7 @@ SIGNATURES = {
 # test hooks outside the public header
 _EXTRA = {"llada_gemm_force_tile_rows": (None, [C.c_int]), "llada_gemm_use_pipelined": (None, [C.c_int]),
           "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]),
-          "llada_gemm_profile_begin": (C.c_int, [C.c_int, C.c_int]),
+          "llada_gemm_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_longlong]),
           "llada_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)])}
 
 _lib = None

@@ -27,6 +27,10 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// SiLU in float32: x * 1/(1 + e^-x) with the hardware exponential and reciprocal (1 ulp each); every
+// caller rounds the result to bf16 straight away.
+__device__ __forceinline__ float silu_f32(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {

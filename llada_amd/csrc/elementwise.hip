@@ -18,6 +18,19 @@ __global__ void embed_kernel(const bf16_t* __restrict__ wte, const int64_t* __re
     }
 }
 
+// ---- row gather: out[r, :] = in[rows[r], :] (compacts the rows the LM head needs) ----------------
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ in, const int32_t* __restrict__ rows, bf16_t* __restrict__ out,
+                                   int64_t n_rows, int d, int64_t n_in) {
+    const int chunks = d / 8;
+    for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        int64_t src_row = rows[r];
+        src_row = src_row < 0 ? 0 : (src_row >= n_in ? n_in - 1 : src_row);  // host validates; never read out of bounds
+        const u32x4* src = (const u32x4*)(in + src_row * d);
+        u32x4* dst = (u32x4*)(out + r * d);
+        for (int c = threadIdx.x; c < chunks; c += blockDim.x) dst[c] = src[c];
+    }
+}
+
 // ---- RMSNorm ---------------------------------------------------------------------------------
 // One 256-thread workgroup per row; d <= 256*8*MAXV elements are kept in registers between the
 // sum-of-squares pass and the scaling pass.
@@ -112,7 +125,7 @@ __global__ void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gf = bf16_to_f32(g[e]);
-            const float act = round_bf16(gf / (1.0f + __expf(-gf)));
+            const float act = round_bf16(silu_f32(gf));
             o[e] = f32_to_bf16(act * bf16_to_f32(u[e]));
         }
         *(u16x8*)(out + m * F + c * 8) = o;
@@ -120,6 +133,17 @@ __global__ void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict_
 }
 
 }  // namespace
+
+extern "C" int llada_gather_rows_bf16(const void* in, const int32_t* rows, void* out, int64_t n_rows, int32_t d,
+                                      int64_t n_in, void* stream) {
+    LLADA_CHECK_ARG(in && rows && out && n_rows > 0 && n_in > 0, "gather_rows: bad argument");
+    LLADA_CHECK_SUPPORTED(d % 8 == 0, "gather_rows: d=%d must be a multiple of 8", d);
+    const int grid = (int)(n_rows < 4096 ? n_rows : 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, rows,
+                       (bf16_t*)out, n_rows, d, n_in);
+    LLADA_CHECK_LAUNCH("gather_rows_kernel");
+    return LLADA_OK;
+}
 
 extern "C" int llada_embed_bf16(const void* wte, const int64_t* ids, void* out, int64_t n_tokens, int32_t d,
                                 int64_t vocab, void* stream) {

@@ -32,8 +32,9 @@ Layout make_layout(const llada_config& c, int64_t M, int64_t R) {
     o.hf = take(R * d * 2);
     // split-K scratch for the small-M regime (every projection of a layer, and the LM head)
     size_t sk = 0;
-    const size_t shapes[5][3] = {{(size_t)M, 3 * d, d}, {(size_t)M, d, d}, {(size_t)M, 2 * F, d}, {(size_t)M, d, F},
-                                 {(size_t)R, (size_t)c.vocab_size, d}};
+    const size_t shapes[8][3] = {{(size_t)M, 3 * d, d}, {(size_t)M, d, d}, {(size_t)M, 2 * F, d}, {(size_t)M, d, F},
+                                 {(size_t)R, (size_t)c.vocab_size, d},
+                                 {(size_t)R, d, d}, {(size_t)R, 2 * F, d}, {(size_t)R, d, F}};   // last layer, wanted rows only
     for (auto& sh : shapes) {
         const size_t b = llada_gemm_workspace_bytes((int64_t)sh[0], (int32_t)sh[1], (int32_t)sh[2]);
         sk = b > sk ? b : sk;
@@ -87,6 +88,14 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     const size_t skb = lay.splitk_bytes;
     const int d = c.d_model, F = c.mlp_hidden, V = c.vocab_size;
 
+    // In the last layer only the wanted rows matter once attention has mixed the tokens: they are
+    // compacted (attention output and residual stream) and the output projection, the MLP and the
+    // final norm run on those rows alone.  Scratch: the qkv buffer is dead after attention.
+    const bool prune = logit_rows != nullptr && (int64_t)n_logit_rows * 2 <= M;
+    const int64_t R = n_logit_rows;
+    void* xc = qkv;                                     // [R, d] compacted residual stream
+    void* hc = (unsigned char*)qkv + (size_t)R * d * 2; // [R, d] its norm
+
     TRY(llada_embed_bf16(w->wte, ids, x, M, d, V, stream));
     for (int l = 0; l < c.n_layers; ++l) {
         TRY(llada_rmsnorm_bf16(x, w->attn_norm[l], h, M, d, c.rms_eps, nullptr, stream));
@@ -99,21 +108,36 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
             TRY(llada_rope_bf16(qkv, rope_cos, rope_sin, n_seq, seq_len, c.n_heads, stream));
         }
         TRY(llada_attn_bidir_bf16(qkv, key_mask, att, n_seq, seq_len, c.n_heads, stream));
-        TRY(llada_gemm_bf16(att, w->wo[l], x, M, d, d, d, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0, sk, skb, stream));
-        TRY(llada_rmsnorm_bf16(x, w->ff_norm[l], h, M, d, c.rms_eps, nullptr, stream));
+        int64_t Ml = M;      // rows from here to the end of the layer
+        void* xl = x;        // residual stream of those rows
+        void* al = att;      // attention output of those rows
+        void* hl = h;
+        if (prune && l == c.n_layers - 1) {
+            TRY(llada_gather_rows_bf16(att, logit_rows, h, R, d, M, stream));   // h is free until the second norm
+            TRY(llada_gather_rows_bf16(x, logit_rows, xc, R, d, M, stream));
+            Ml = R;
+            xl = xc;
+            al = h;
+            hl = hc;
+        }
+        TRY(llada_gemm_bf16(al, w->wo[l], xl, Ml, d, d, d, d, LLADA_EPI_RESIDUAL, xl, d, nullptr, nullptr, 0, sk, skb, stream));
+        TRY(llada_rmsnorm_bf16(xl, w->ff_norm[l], hl, Ml, d, c.rms_eps, nullptr, stream));
         if (w->packed) {
-            TRY(llada_gemm_bf16(h, w->wgu[l], act, M, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr,
+            TRY(llada_gemm_bf16(hl, w->wgu[l], act, Ml, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr,
                                 0, sk, skb, stream));
         } else {
-            TRY(llada_gemm_bf16(h, w->wgu[l], gu, M, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+            TRY(llada_gemm_bf16(hl, w->wgu[l], gu, Ml, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
                                 nullptr, 0, sk, skb, stream));
-            TRY(llada_swiglu_bf16(gu, act, M, F, stream));
+            TRY(llada_swiglu_bf16(gu, act, Ml, F, stream));
         }
-        TRY(llada_gemm_bf16(act, w->wdown[l], x, M, d, F, F, d, LLADA_EPI_RESIDUAL, x, d, nullptr, nullptr, 0,
+        TRY(llada_gemm_bf16(act, w->wdown[l], xl, Ml, d, F, F, d, LLADA_EPI_RESIDUAL, xl, d, nullptr, nullptr, 0,
                             sk, skb, stream));
     }
-    TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, n_logit_rows, d, c.rms_eps, logit_rows, stream));
-    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, n_logit_rows, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+    if (prune && c.n_layers > 0)
+        TRY(llada_rmsnorm_bf16(xc, w->ln_f, hf, R, d, c.rms_eps, nullptr, stream));
+    else
+        TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, R, d, c.rms_eps, logit_rows, stream));
+    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, R, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
                         nullptr, 0, sk, skb, stream));
     return LLADA_OK;
 }

@@ -75,6 +75,23 @@ def test_true_shape_layer(lib):
     assert max_rel(got, ref) <= 2e-2, max_rel(got, ref)
 
 
+def test_true_shape_last_layer_rows_only(lib):
+    """With few wanted rows the last layer's output projection and MLP run on those rows alone
+    (small-M GEMMs, split-K): same logits as the all-rows forward up to accumulation order."""
+    from oracle.bf16 import ulp_distance
+    ocfg = OCfg(d_model=4096, n_layers=2, n_heads=32, mlp_hidden=12288, vocab_size=1024)
+    W = init_weights(ocfg, seed=4, std=0.02, head_scale=8.0)
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(2))
+    ids = torch.from_numpy(g.integers(0, 1024, size=(2, 96), dtype=np.int64)).cuda()
+    full = model(ids).logits.reshape(-1, 1024).float().cpu().numpy()
+    rows = np.concatenate([np.arange(40, 72), np.arange(96 + 40, 96 + 72)]).astype(np.int32)
+    sub = model.forward_rows(ids, None, torch.from_numpy(rows).cuda()).float().cpu().numpy()
+    ref = full[rows]
+    assert max_rel(sub, ref) <= 2.0 ** -7, max_rel(sub, ref)      # one bf16 step of the largest logit
+    assert (ulp_distance(sub, ref) <= 1).mean() >= 0.95            # small logits move by more ulps
+
+
 def test_generate_end_to_end(lib, tiny):
     """llada_amd.generate on the HIP model (fast path: LM head on the block rows only), batch with
     left padding.  Every step is checked teacher-forced: the oracle's confidence_step on the HIP

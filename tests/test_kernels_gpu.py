@@ -150,6 +150,16 @@ def test_gemm_splitk_auto_small_m(lib):
     assert ulp_distance(a, b).max() <= 1 or np.abs(a - b).max() <= 2e-2
 
 
+def test_gather_rows(lib):
+    g = np.random.Generator(np.random.PCG64(41))
+    src = bf(round_bf16(g.standard_normal((300, 256), dtype=np.float32)))
+    rows = torch.from_numpy(g.integers(0, 300, size=77).astype(np.int32)).cuda()
+    out = torch.empty(77, 256, dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.llada_gather_rows_bf16(src.data_ptr(), rows.data_ptr(), out.data_ptr(), 77, 256, 300, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, src[rows.long()])
+
+
 @pytest.mark.parametrize("shape", [(512, 512, 256), (3072, 1024, 4096), (130, 768, 1024)])
 def test_gemm_random(lib, shape):
     M, N, K = shape
