@@ -157,6 +157,13 @@ def main():
         R = B * bl
         lin = cfg.n_layers * (4 * d * d + 3 * d * F) - (d * d + 3 * d * F)
         flops_step = 2.0 * M * lin + 2.0 * R * (d * d + 3 * d * F) + 2.0 * R * d * V + M * 4.0 * L * d * cfg.n_layers
+        # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes (counters
+        # cannot be read from inside the process); the committed record is quoted, null without it
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_gateup_traffic.json")
+        if B * L == 3072 and os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                traffic = json.load(fh).get("traffic_bytes")
         rec = {
             "metric": "generated tokens/sec/node, LLaDA-8B gen256 steps256 blk32; ms/denoise step",
             "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": K_, "warmup": W_,
@@ -169,7 +176,7 @@ def main():
             "mfma_util_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<.,SWIGLU> (gate/up projection)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": n_s.value, "avg_launch_ms": round(gemm_ms, 4),
                          "flops_per_launch": gemm_flops},
         }
