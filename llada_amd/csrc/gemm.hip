@@ -40,7 +40,6 @@ struct GemmParams {
     int no_store;   // diagnostic: skip the epilogue stores (timing experiments only)
     int band_m;     // M tiles per band of the tile walk
     int remap;      // 1: XCD-aware block -> tile map
-    int plain_store;  // diagnostic: ordinary instead of non-temporal output stores
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -92,14 +91,16 @@ __device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int 
 // writes) and leave as 16 bytes per lane, 8 lanes per 128-byte row: whole cache lines.  The
 // residual is read with the same full-line pattern during the write-out.
 // The caller guarantees that no DMA or LDS read of the main loop is outstanding (barrier).
-template <int MFR, int EPI>
+// MGP = m fragments staged per pass (0: as many as the idle pipeline stages hold); `split` = which
+// float32 slab a partial tile goes to.
+template <int MFR, int EPI, int MGP = 0>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR][4], int m0, int n0, int wm, int wn,
-                                           int fr, int fq, unsigned char* smem, int wave, int lane) {
+                                           int fr, int fq, unsigned char* smem, int wave, int lane, int split) {
     if (p.no_store == 1) return;
     if constexpr (EPI == EPI_PARTIAL) {
         const int m_base = m0 + wm * MFR * 16 + fr;
         const int n_base = n0 + wn * 64 + fq * 4;
-        float* slab = p.slab + (size_t)(blockIdx.x / p.n_tiles) * p.M * p.N;
+        float* slab = p.slab + (size_t)split * p.M * p.N;
 #pragma unroll
         for (int mf = 0; mf < MFR; ++mf) {
             const int m = m_base + mf * 16;
@@ -115,15 +116,46 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
         constexpr bool SWI = (EPI == LLADA_EPI_SWIGLU);
         constexpr int OUTC = SWI ? 32 : 64;            // output columns of this wave
         constexpr int ROWB = OUTC * 2 + 16;            // LDS row stride in bytes
-        constexpr int MG = (MFR == 8) ? 4 : MFR;       // m fragments per pass (LDS budget)
+        constexpr int MG = MGP ? MGP : ((MFR == 8) ? 4 : MFR);   // m fragments per pass (LDS budget)
         constexpr int LPR = OUTC * 2 / 16;             // lanes per output row in the write-out
         constexpr int RPI = 64 / LPR;                  // rows per write-out instruction
         unsigned char* my = smem + wave * (MG * 16 * ROWB);
         const int out_n0 = SWI ? (n0 + wn * 64) / 2 : n0 + wn * 64;   // first output column of the wave
         const int out_cols = SWI ? p.N / 2 : p.N;
         [[maybe_unused]] const bool rope = n0 < p.rope_cols;          // uniform per tile (rope_cols % 256 == 0)
+        constexpr int NI = MG * 16 / RPI;              // write-out instructions per pass
+        const int r_in = lane / LPR, chunk = lane % LPR;
+        const int n = out_n0 + chunk * 8;
+        const int n_ld = min(n, out_cols - 8);         // in-bounds column for unconditional loads
 #pragma unroll
         for (int pass = 0; pass < MFR / MG; ++pass) {
+            // All global loads of a pass (residual rows, rotary tables) are issued up front and
+            // unconditionally (addresses clamped into the matrix), so they travel together: loaded
+            // one by one behind a bounds branch, each costs a full L2 round trip (12 in a row).
+            [[maybe_unused]] u32x4 resid[NI];
+            if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int m = m0 + wm * MFR * 16 + pass * MG * 16 + i * RPI + r_in;
+                    resid[i] = *(const u32x4*)(p.R + (size_t)min(m, (int)p.M - 1) * p.ldr + n_ld);
+                }
+            }
+            [[maybe_unused]] f32x4 rc[MG][2], rs[MG][2];
+            if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
+                if (rope) {
+#pragma unroll
+                    for (int ml = 0; ml < MG; ++ml) {
+                        const int m = m0 + wm * MFR * 16 + (pass * MG + ml) * 16 + fr;
+                        const int pos = min(m, (int)p.M - 1) % p.seq_len;
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const int j = (wn & 1) * 32 + pr * 16 + fq * 4;  // rotary frequency of element 0
+                            rc[ml][pr] = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
+                            rs[ml][pr] = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
+                        }
+                    }
+                }
+            }
             // ---- registers -> LDS (bf16) ----
 #pragma unroll
             for (int ml = 0; ml < MG; ++ml) {
@@ -140,16 +172,12 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                 } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
                     // packed head layout: 16-column blocks 0-15 | 64-79 | 16-31 | 80-95 | ...: fragments
                     // (2pr, 2pr+1) are rotary partners.  Columns >= rope_cols (V) pass through.
-                    const int m = m0 + wm * MFR * 16 + mf * 16 + fr;
-                    const int pos = min(m, p.M - 1) % p.seq_len;
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         const f32x4 x1 = acc[mf][2 * pr], x2 = acc[mf][2 * pr + 1];
                         f32x4 o1 = x1, o2 = x2;
                         if (rope) {
-                            const int j = (wn & 1) * 32 + pr * 16 + fq * 4;  // rotary frequency of element 0
-                            const f32x4 c = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
-                            const f32x4 sn = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
+                            const f32x4 c = rc[ml][pr], sn = rs[ml][pr];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float a = round_bf16(x1[e]), b = round_bf16(x2[e]);
@@ -184,34 +212,29 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                 }
             }
             // ---- LDS -> global, whole rows ----
-            const int r_in = lane / LPR, chunk = lane % LPR;
-            const int n = out_n0 + chunk * 8;
+            // Projection outputs (tens of MB, read next by another kernel) leave with the
+            // non-temporal hint; the residual stream (25 MB, re-read at once by the norm) stays an
+            // ordinary store.
 #pragma unroll
-            for (int i = 0; i < MG * 16 / RPI; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int rl = i * RPI + r_in;
                 const int m = m0 + wm * MFR * 16 + pass * MG * 16 + rl;
                 u32x4 v = *(const u32x4*)(my + rl * ROWB + chunk * 16);
-                if (m < p.M && n < out_cols) {
-                    if constexpr (EPI == LLADA_EPI_RESIDUAL) {
-                        const u32x4 r = *(const u32x4*)(p.R + (size_t)m * p.ldr + n);
+                if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+                    const u32x4 r = resid[i];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float lo = bf16_to_f32(r[e] & 0xFFFF) + bf16_to_f32(v[e] & 0xFFFF);
-                            const float hi = bf16_to_f32(r[e] >> 16) + bf16_to_f32(v[e] >> 16);
-                            v[e] = pack_bf16x2(lo, hi);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf16_to_f32(r[e] & 0xFFFF) + bf16_to_f32(v[e] & 0xFFFF);
+                        const float hi = bf16_to_f32(r[e] >> 16) + bf16_to_f32(v[e] >> 16);
+                        v[e] = pack_bf16x2(lo, hi);
                     }
-                    // Projection outputs (tens of MB, read next by another kernel) leave with the
-                    // non-temporal hint: written back as ordinary dirty L2 lines, the burst of all
-                    // CUs finishing a round of tiles together costs 5-10 % of the kernel.  The
-                    // residual stream (25 MB, re-read at once by the norm) stays an ordinary store.
-                    if (p.no_store != 2) {
-                        u32x4* dst = (u32x4*)(p.C + (size_t)m * p.ldc + n);
-                        if (EPI == LLADA_EPI_RESIDUAL || p.plain_store)
-                            *dst = v;
-                        else
-                            __builtin_nontemporal_store(v, dst);
-                    }
+                }
+                if (m < p.M && n < out_cols && p.no_store != 2) {
+                    u32x4* dst = (u32x4*)(p.C + (size_t)m * p.ldc + n);
+                    if constexpr (EPI == LLADA_EPI_RESIDUAL)
+                        *dst = v;
+                    else
+                        __builtin_nontemporal_store(v, dst);
                 }
             }
         }
@@ -299,7 +322,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
     }
 
     __syncthreads();  // all waves are done reading the last stage: the LDS is free
-    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane);
+    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane, blockIdx.x / p.n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -500,7 +523,213 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills must land before the LDS is released
 
     __syncthreads();  // all waves are done reading the last stage: the LDS is free
-    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane);
+    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane, blockIdx.x / p.n_tiles);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the pipelined kernel: a workgroup walks the work items b, b+G, b+2G, ... (G =
+// grid size, a multiple of 8, so all its items map to the XCD it runs on) as ONE continuous stream
+// of K tiles.  The refills issued in an item's last two K tiles already fetch the first two K
+// tiles of the next item, and the fragment reads run ahead in the same way, so the DMA pipeline
+// never drains between output tiles: the only per-tile cost left is the write-out itself, which
+// uses its own LDS slice next to the two pipeline stages (2 m-fragments per pass and wave) while
+// the next item's operands are already landing.  Stores count in vmcnt like the DMA, so the first
+// waits after a write-out are stricter than needed (never weaker).
+template <int MFR, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_stream_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = MFR * 32;
+    constexpr int HA = MFR / 2;
+    constexpr int AH_ROWS = MFR * 16;
+    constexpr int AH_BYTES = AH_ROWS * ROW_BYTES;
+    constexpr int BH_BYTES = 128 * ROW_BYTES;
+    constexpr int STAGE = 2 * AH_BYTES + 2 * BH_BYTES;
+    constexpr int A_GROUPS = AH_ROWS / 8;
+    constexpr int NB = 2;
+    constexpr bool two_a = A_GROUPS > 8;
+    constexpr bool half_a = A_GROUPS == 12;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    unsigned char* epi_lds = smem + 2 * STAGE;
+
+    const int nk = p.K / BK / p.splits;
+    const int n_items = p.n_tiles * p.splits;
+    const int G = gridDim.x;
+    int item = blockIdx.x;
+
+    // ---- lane constants of the DMA sources: tile row and pre-swizzled chunk per (half, piece) ----
+    int a_trow[2][2], a_chunk[2], b_tcol[2][2], b_chunk[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rho = (u == 0) ? wave * 8 + (lane >> 3)
+                                 : (half_a ? 64 + wave * 4 + ((lane & 31) >> 3) : min(wave + 8, A_GROUPS - 1) * 8 + (lane >> 3));
+        a_chunk[u] = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
+        const int rb = (wave + 8 * u) * 8 + (lane >> 3);
+        b_chunk[u] = ((lane & 7) ^ ((rb >> 1) & 7)) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            a_trow[h][u] = (rho / (MFR * 8)) * (MFR * 16) + h * (MFR * 8) + rho % (MFR * 8);
+            b_tcol[h][u] = (rb >> 5) * 64 + h * 32 + (rb & 31);
+        }
+    }
+    const bf16_t* a_src[2][2];
+    const bf16_t* b_src[2][2];
+    auto decode = [&](int it, int& m0, int& n0, int& split) {
+        int tm, tn;
+        tile_of_block(it % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
+        m0 = tm * BM;
+        n0 = tn * BN;
+        split = it / p.n_tiles;
+    };
+    auto set_sources = [&](int m0, int n0, int split) {
+        const size_t k_first = (size_t)split * nk * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a_src[h][u] = p.A + (size_t)min(m0 + a_trow[h][u], p.M - 1) * p.lda + k_first + a_chunk[u];
+                b_src[h][u] = p.W + (size_t)min(n0 + b_tcol[h][u], p.N - 1) * p.K + k_first + b_chunk[u];
+            }
+    };
+
+    // kt = K tile of the item the sources point at; par = LDS stage (parity of the stream position)
+    auto issue_a = [&](int h, int kt, int par) {
+        const int ks = min(kt, nk - 1) * BK;
+        unsigned char* base = smem + par * STAGE + h * AH_BYTES;
+        glds16(a_src[h][0] + ks, base + wave * 1024);
+        if constexpr (half_a)
+            glds16_lo32(a_src[h][1] + ks, base + 8 * 1024 + wave * 512);
+        else if constexpr (two_a)
+            glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
+    };
+    auto issue_b = [&](int h, int kt, int par) {
+        const int ks = min(kt, nk - 1) * BK;
+        unsigned char* base = smem + par * STAGE + 2 * AH_BYTES + h * BH_BYTES;
+        glds16(b_src[h][0] + ks, base + wave * 1024);
+        glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = fr >> 1;
+    const int c0 = ((0 + fq) ^ swz) * 16, c1 = ((4 + fq) ^ swz) * 16;
+    const int a_off = (wm * (MFR * 8) + fr) * ROW_BYTES;
+    const int b_off = 2 * AH_BYTES + (wn * 32 + fr) * ROW_BYTES;
+
+    auto read_a = [&](bf16x8 (&r)[HA][2], int h, int par) {
+        const unsigned char* base = smem + par * STAGE + h * AH_BYTES + a_off;
+#pragma unroll
+        for (int mf = 0; mf < HA; ++mf) {
+            r[mf][0] = *(const bf16x8*)(base + mf * 16 * ROW_BYTES + c0);
+            r[mf][1] = *(const bf16x8*)(base + mf * 16 * ROW_BYTES + c1);
+        }
+    };
+    auto read_b = [&](bf16x8 (&r)[2][2], int h, int par) {
+        const unsigned char* base = smem + par * STAGE + h * BH_BYTES + b_off;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            r[nf][0] = *(const bf16x8*)(base + nf * 16 * ROW_BYTES + c0);
+            r[nf][1] = *(const bf16x8*)(base + nf * 16 * ROW_BYTES + c1);
+        }
+    };
+
+    f32x4 acc[MFR][4];
+#pragma unroll
+    for (int i = 0; i < MFR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[2][2], int ha, int hb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mf = 0; mf < HA; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    acc[ha * HA + mf][hb * 2 + nf] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a[mf][ks], acc[ha * HA + mf][hb * 2 + nf], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+#define WAIT_END(n_b, n_a) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((n_b) * NB + (n_a) * (two_a ? 2 : 1)) : "memory")
+#define BARRIER()                           \
+    do {                                    \
+        __builtin_amdgcn_s_barrier();       \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+#define PHASE(issue_stmt, read_stmt, mma_stmt)  \
+    do {                                        \
+        issue_stmt;                             \
+        read_stmt;                              \
+        BARRIER();                              \
+        mma_stmt;                               \
+        WAIT_END(2, 2);                         \
+        BARRIER();                              \
+    } while (0)
+
+    bf16x8 X[HA][2], Y[HA][2], P[2][2], Q[2][2];
+
+    int m0, n0, split;
+    decode(item, m0, n0, split);
+    set_sources(m0, n0, split);
+    issue_b(0, 0, 0);
+    issue_a(0, 0, 0);
+    issue_a(1, 0, 0);
+    issue_b(1, 0, 0);
+    issue_b(0, 1, 1);
+    issue_a(0, 1, 1);
+    issue_a(1, 1, 1);
+    issue_b(1, 1, 1);
+    WAIT_END(3, 3);
+    BARRIER();
+    read_a(X, 0, 0);
+    read_b(P, 0, 0);
+    WAIT_END(2, 2);
+    BARRIER();
+    if (wm == 1) BARRIER();  // stagger: the upper half runs one barrier behind
+
+    for (;;) {
+        int ik = 2;          // next K tile to fetch, relative to the item the sources point at
+        int nm0 = 0, nn0 = 0, nsplit = 0;
+        bool more = false;
+        for (int t = 0; t < nk; t += 2) {
+            if (t == nk - 2) {   // the last two refills of this item fetch the head of the next one
+                more = item + G < n_items;
+                if (more) {
+                    decode(item + G, nm0, nn0, nsplit);
+                    set_sources(nm0, nn0, nsplit);
+                    ik = 0;
+                }
+            }
+            PHASE(issue_b(0, ik, 0), read_a(Y, 1, 0), mma(X, P, 0, 0));
+            PHASE(issue_a(0, ik, 0), read_b(Q, 1, 0), mma(Y, P, 1, 0));
+            PHASE(issue_a(1, ik, 0), read_b(P, 0, 1), mma(Y, Q, 1, 1));
+            PHASE(issue_b(1, ik, 0), read_a(Y, 0, 1), mma(X, Q, 0, 1));
+            PHASE(issue_b(0, ik + 1, 1), read_a(X, 1, 1), mma(Y, P, 0, 0));
+            PHASE(issue_a(0, ik + 1, 1), read_b(Q, 1, 1), mma(X, P, 1, 0));
+            PHASE(issue_a(1, ik + 1, 1), read_b(P, 0, 0), mma(X, Q, 1, 1));
+            PHASE(issue_b(1, ik + 1, 1), read_a(X, 0, 0), mma(Y, Q, 0, 1));
+            ik += 2;
+        }
+        store_tile<MFR, EPI, 2>(p, acc, m0, n0, wm, wn, fr, fq, epi_lds, wave, lane, split);
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < MFR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        item += G;
+        m0 = nm0;
+        n0 = nn0;
+        split = nsplit;
+    }
+    if (wm == 0) BARRIER();  // the lower half waits for the upper half's last interval
+#undef WAIT_END
+#undef PHASE
+#undef BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills must land before the LDS is released
 }
 
 // Elementwise epilogue on float32 sums, identical to store_tile's: v1 = columns n1..n1+3 of row m,
@@ -583,7 +812,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
-int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel
+int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel, 2 the persistent stream kernel, 3 never it
+int g_stream_grid = 256;  // workgroups of the persistent kernel (one per CU)
 int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
 int g_force_splits = 0;   // test hook: > 0 forces the split count when a workspace is given
 size_t g_slab_bytes = 0;  // capacity of the caller's split-K workspace for the current call
@@ -617,6 +847,28 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
     const int nk = q.K / BK / q.splits;
     if constexpr (MFR != 8) {  // the 256-row tile does not fit the pipelined kernel's register budget
+        // The persistent form pays off where a workgroup gets several tiles and the write-out issues no
+        // loads of its own (gate/up projection: 6 tiles per CU at M = 3072); elsewhere it is neutral or
+        // slower in situ.  Hook values: 2 = always, 3 = never.
+        const bool stream_ok = g_use_pipelined == 2 ||
+                               (g_use_pipelined == 1 && EPI == LLADA_EPI_SWIGLU && grid >= 2 * g_stream_grid);
+        if (stream_ok && nk >= 4 && (nk & 1) == 0) {
+            constexpr int stream_lds = lds + 8 * 2 * 16 * 144;   // + the write-out slices (2 m-fragments per wave)
+            static bool attr3_set = false;
+            if (!attr3_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_stream_kernel<MFR, EPI>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds);
+                if (e != hipSuccess) {
+                    llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+                    return LLADA_ERR_HIP;
+                }
+                attr3_set = true;
+            }
+            const int sgrid = grid < g_stream_grid ? grid : g_stream_grid;
+            hipLaunchKernelGGL((gemm_bf16_stream_kernel<MFR, EPI>), dim3(sgrid), dim3(NTHREADS), stream_lds, stream, q);
+            LLADA_CHECK_LAUNCH("gemm_bf16_stream_kernel");
+            return LLADA_OK;
+        }
         if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
             static bool attr2_set = false;
             if (!attr2_set) {
@@ -649,7 +901,6 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
 }
 
 int g_no_store = 0;       // diagnostic hook
-int g_plain_store = 0;    // diagnostic hook
 template <int MFR, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = MFR * 32;
@@ -657,7 +908,6 @@ int launch(const GemmParams& p, hipStream_t stream) {
     q.band_m = g_band_m;
     q.remap = g_remap;
     q.no_store = g_no_store;
-    q.plain_store = g_plain_store;
     q.tiles_m = (int)((p.M + BM - 1) / BM);
     q.tiles_n = (p.N + BN - 1) / BN;
     q.n_tiles = q.tiles_m * q.tiles_n;
@@ -712,9 +962,9 @@ int dispatch_mfr(const GemmParams& p, int mfr, hipStream_t stream) {
 static int g_force_mfr = 0;
 extern "C" void llada_gemm_force_tile_rows(int rows) { g_force_mfr = rows / 32; }
 extern "C" void llada_gemm_use_pipelined(int on) { g_use_pipelined = on; }
+extern "C" void llada_gemm_stream_grid(int n) { g_stream_grid = n > 0 ? (n & ~7) > 0 ? (n & ~7) : 8 : 256; }
 extern "C" void llada_gemm_force_splits(int splits) { g_force_splits = splits; }
 extern "C" void llada_gemm_no_store(int on) { g_no_store = on; }
-extern "C" void llada_gemm_plain_store(int on) { g_plain_store = on; }
 
 extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
     g_band_m = band_m > 0 ? band_m : 8;

@@ -69,21 +69,50 @@ def test_gemm_exact_integers(lib, shape, tile_rows):
 
 @pytest.mark.parametrize("tile_rows", [128, 192])
 def test_gemm_pipelined_equals_simple(lib, tile_rows):
-    """The quarter-tile pipelined main loop and the simple two-stage loop accumulate every output in
-    the same k order: bit-identical results on random data, ragged M and N, long K."""
+    """The quarter-tile pipelined main loop, its persistent form (several tiles per workgroup as one
+    continuous K stream; 8 and 24 workgroups over ~28-32 tiles) and the simple two-stage loop
+    accumulate every output in the same k order: bit-identical results on random data, ragged M and
+    N, long K, for every epilogue."""
+    from llada_amd.weights import pack_gate_up, pack_qkv
     M, N, K = 1000, 776, 2048
     g = np.random.Generator(np.random.PCG64(21))
     A = bf(round_bf16(g.standard_normal((M, K), dtype=np.float32)))
     W = bf(round_bf16(g.standard_normal((N, K), dtype=np.float32) * 0.05))
+    R = bf(round_bf16(g.standard_normal((M, N), dtype=np.float32)))
+    # fused-epilogue operands: 2 heads of 128 (rope), 384 hidden units (SwiGLU), K = 256 * 8
+    n_seq, L, H, F = 4, 250, 2, 384
+    d = H * 128
+    A2 = bf(round_bf16(g.standard_normal((n_seq * L, K), dtype=np.float32)))
+    Wq, Wk, Wv = (bf(round_bf16(g.standard_normal((d, K), dtype=np.float32) * 0.05)) for _ in range(3))
+    Wg, Wu = (bf(round_bf16(g.standard_normal((F, K), dtype=np.float32) * 0.05)) for _ in range(2))
+    cos, sin = omodel.rope_tables(L, 128, 500000.0)
+    ct, st = dev(cos), dev(sin)
+    qkv_w, gu_w = pack_qkv(Wq, Wk, Wv, H), pack_gate_up(Wg, Wu)
+
+    def run_all():
+        return (gemm(lib, A, W), gemm(lib, A, W, epi=1, R=R),
+                gemm(lib, A2, qkv_w, epi=2, cos=ct, sin=st, seq_len=L), gemm(lib, A2, gu_w, epi=3, out_cols=F))
+
     lib.llada_gemm_force_tile_rows(tile_rows)
     try:
-        fast = gemm(lib, A, W)
         lib.llada_gemm_use_pipelined(0)
-        slow = gemm(lib, A, W)
+        slow = run_all()
+        lib.llada_gemm_use_pipelined(3)
+        fast = run_all()
+        lib.llada_gemm_use_pipelined(2)
+        streams = []
+        for grid in (8, 24, 256):
+            lib.llada_gemm_stream_grid(grid)
+            streams.append(run_all())
     finally:
+        lib.llada_gemm_stream_grid(256)
         lib.llada_gemm_use_pipelined(1)
         lib.llada_gemm_force_tile_rows(0)
-    assert torch.equal(fast, slow)
+    for a, b in zip(slow, fast):
+        assert torch.equal(a, b)
+    for st_ in streams:
+        for a, b in zip(slow, st_):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("splits", [2, 4, 8])
