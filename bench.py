@@ -91,10 +91,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LLADA_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks then share devices and the timing reduce runs on the host); the real run is RCCL
+    backend = os.environ.get("LLADA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     cfg = LLaDAConfig(n_layers=args.layers)
@@ -139,7 +146,7 @@ def main():
     lib.llada_gemm_profile_end(C.byref(tot_ms), C.byref(n_s))
     torch.cuda.synchronize()
     elapsed = state["t1"] - state["t0"]
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -174,7 +181,7 @@ def main():
                        "layers": cfg.n_layers, "rows_per_gpu": B, "seq_len": L, "parallelism": f"dp{world}"},
             "step_tflops_executed": round(flops_step / 1e12, 3),
             "mfma_util_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<.,SWIGLU> (gate/up projection)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_stream_kernel<6,SWIGLU> (gate/up projection, M = rows_per_gpu x seq_len)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": n_s.value, "avg_launch_ms": round(gemm_ms, 4),
