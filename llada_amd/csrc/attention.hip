@@ -5,206 +5,39 @@
 // the whole sequence, so there is no causal mask, only an optional key-padding mask
 // (generate.py:63-64).
 //
-// One workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries.
-// Per 64-key tile: S^T = K Q^T on v_mfma_f32_32x32x16_bf16 (keys on the accumulator rows, so a
-// query's scores sit in one lane's registers and the row max/sum need no cross-lane work beyond
-// one half-swap), P is converted to bf16 in registers and used directly as the B operand of
-// O^T += V^T P^T; the V^T fragments come out of the row-major V tile in LDS through the
-// transposing ds_read_b64_tr_b16.  K/V tiles are register-staged: the next tile's global loads
-// are in flight while the current tile is computed.
+// One workgroup = NW waves (4 unless the sequence is shorter than 128), 32 queries per wave, all
+// of one (sequence, head).  Per 64-key tile: S^T = K Q^T on v_mfma_f32_32x32x16_bf16 (keys on the
+// accumulator rows, so a query's scores sit in one lane's registers and the row max/sum need no
+// cross-lane work beyond one half-swap), P is converted to bf16 in registers and used directly as
+// the B operand of O^T += V^T P^T; the V^T fragments come out of the row-major V tile in LDS
+// through the transposing ds_read_b64_tr_b16.
+//
+// K/V tiles are brought in by 16-byte LDS-DMA into two buffers, one barrier per tile: the next
+// tile's DMA is in flight while the current one is computed and no registers are spent on staging.
+// LDS rows are 256 B, unpadded; bank conflicts are avoided by XOR swizzles applied on the DMA
+// source address and on the read address:
+//   K (ds_read_b128, lanes = 32 keys x 2 chunks):   16-byte chunk c of row k sits at c ^ (k & 15)
+//   V (ds_read_b64_tr_b16, lanes = 4 keys x 64 B):  64-byte slot s of row k sits at s ^ (k & 3)
 #include "common.h"
 
 namespace {
 
 constexpr int HD = 128;
-constexpr int QB = 128;         // queries per workgroup
 constexpr int KT = 64;          // keys per tile
-constexpr int K_STRIDE = 272;   // bytes per K row in LDS: 256 + 16 -> conflict-free ds_read_b128
-constexpr int V_STRIDE = 320;   // bytes per V row in LDS: 256 + 64 -> conflict-free ds_read_b64_tr_b16
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
 }
 
-__global__ void __launch_bounds__(256, 2)
-attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out,
-                  int L, int d, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * K_STRIDE];
-    __shared__ __attribute__((aligned(16))) unsigned char v_lds[KT * V_STRIDE];
-    __shared__ __attribute__((aligned(16))) float bias_lds[KT];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hg = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QB + wave * 32;
-    const size_t row_stride = (size_t)3 * d;
-    const bf16_t* base = qkv + (size_t)b * L * row_stride + (size_t)h * HD;
-
-    // Q fragments: B operand of S^T = K Q^T, lane holds Q[q0 + r][16*ds + 8*hg .. +7]
-    bf16x8 qf[8];
-    {
-        const int q = min(q0 + r, L - 1);
-        const bf16_t* qp = base + (size_t)q * row_stride + hg * 8;
-#pragma unroll
-        for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 16);
-    }
-
-    f32x16 o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // staging: thread t moves chunk (t & 15) of keys (t >> 4) + 16*i, i = 0..3, for K and V
-    const int s_key = tid >> 4, s_chunk = tid & 15;
-    u32x4 kreg[4], vreg[4];
-    auto load_tile = [&](int kt0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = min(kt0 + s_key + 16 * i, L - 1);
-            const bf16_t* kp = base + (size_t)key * row_stride + d + s_chunk * 8;
-            kreg[i] = *(const u32x4*)kp;
-            vreg[i] = *(const u32x4*)(kp + d);
-        }
-    };
-    auto write_tile = [&](int kt0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = s_key + 16 * i;
-            *(u32x4*)(k_lds + key * K_STRIDE + s_chunk * 16) = kreg[i];
-            *(u32x4*)(v_lds + key * V_STRIDE + s_chunk * 16) = vreg[i];
-        }
-        if (tid < KT) {
-            const int key = kt0 + tid;
-            bool ok = key < L;
-            if (ok && key_mask) ok = key_mask[(size_t)b * L + key] != 0;
-            bias_lds[tid] = ok ? 0.f : -INFINITY;
-        }
-    };
-
-    const int n_tiles = (L + KT - 1) / KT;
-    load_tile(0);
-    for (int t = 0; t < n_tiles; ++t) {
-        const int kt0 = t * KT;
-        __syncthreads();  // every wave is done reading the previous tile
-        write_tile(kt0);
-        __syncthreads();
-        if (t + 1 < n_tiles) load_tile(kt0 + KT);
-
-        // ---- S^T[key][q] for two 32-key blocks ----
-        f32x16 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-#pragma unroll
-        for (int ds = 0; ds < 8; ++ds) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *(const bf16x8*)(k_lds + (kb * 32 + r) * K_STRIDE + (2 * ds + hg) * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
-            }
-        }
-        const bool need_bias = (key_mask != nullptr) || (kt0 + KT > L);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-                if (need_bias) bias = *(const f32x4*)(bias_lds + kb * 32 + 8 * c + 4 * hg);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = s[kb][4 * c + e] * scale_log2e + bias[e];
-                    s[kb][4 * c + e] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(s[kb][e] - m_use);
-                psum += pv;
-                pb[kb][e >> 3][e & 7] = (__bf16)pv;
-            }
-        }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-
-        // ---- O^T[dd][q] += V^T[dd][key] P^T[key][q] ----
-        const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
-        const unsigned char* vbase = v_lds + (4 * hg + q4) * V_STRIDE + (16 * g1 + 4 * p4) * 2;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const unsigned char* vk = vbase + (kb * 32 + 16 * ss) * V_STRIDE;
-#pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    const s16x4 lo = tr_read(vk + db * 64);
-                    const s16x4 hi = tr_read(vk + db * 64 + 8 * V_STRIDE);
-                    u16x8 vv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        vv[e] = (unsigned short)lo[e];
-                        vv[e + 4] = (unsigned short)hi[e];
-                    }
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pb[kb][ss], o[db],
-                                                                    0, 0, 0);
-                }
-            }
-        }
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + r;
-    if (q < L) {
-        bf16_t* op = out + ((size_t)b * L + q) * d + (size_t)h * HD + 4 * hg;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u32x2 w;
-                w[0] = pack_bf16x2(o[db][4 * c] * inv, o[db][4 * c + 1] * inv);
-                w[1] = pack_bf16x2(o[db][4 * c + 2] * inv, o[db][4 * c + 3] * inv);
-                *(u32x2*)(op + db * 32 + 8 * c) = w;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Second form: NW waves per workgroup (32 queries each), K/V tiles brought in by 16-byte LDS-DMA
-// into two buffers, one barrier per tile.  No staging registers, so twelve waves (all 384 queries of
-// a benchmark sequence: K/V are fetched once per (sequence, head)) fit a CU at three waves per SIMD.
-// LDS rows are 256 B, unpadded; bank conflicts are avoided by XOR swizzles applied on the DMA
-// source address and on the read address:
-//   K (ds_read_b128, lanes = 32 keys x 2 chunks):   16-byte chunk c of row k sits at c ^ (k & 15)
-//   V (ds_read_b64_tr_b16, lanes = 4 keys x 64 B):  64-byte slot s of row k sits at s ^ (k & 3)
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
-
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, (NW >= 4 ? 3 : 2))
-attn_bidir_dma_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out,
+__global__ void __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1))
+attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out,
                       int L, int d, float scale_log2e) {
     constexpr int TILE_BYTES = KT * 256;           // one operand, one tile
     constexpr int BUF_BYTES = 2 * TILE_BYTES;      // K then V
@@ -221,18 +54,21 @@ attn_bidir_dma_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict_
 
     // ---- DMA: a tile is 32 pieces of 1 KiB (4 keys x 256 B): pieces 0-15 = K, 16-31 = V ----
     const int p_row = lane >> 4, p_slot = lane & 15;
+    auto issue_piece = [&](int kt0, int buf, int piece) {   // piece is wave-uniform
+        const int is_v = piece >> 4;
+        const int row = (piece & 15) * 4 + p_row;
+        const int chunk = is_v ? ((((p_slot >> 2) ^ (row & 3)) << 2) | (p_slot & 3)) : (p_slot ^ (row & 15));
+        const int key = min(kt0 + row, L - 1);
+        const bf16_t* src = base + (size_t)key * row_stride + d + (size_t)is_v * d + chunk * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(lds + buf * BUF_BYTES + piece * 1024), 16, 0, 0);
+    };
     auto issue_tile = [&](int kt0, int buf) {
+        if constexpr (NW >= 4) {
 #pragma unroll
-        for (int i = 0; i < (32 + NW - 1) / NW; ++i) {
-            const int piece = wave + i * NW;
-            if (piece < 32) {   // wave-uniform
-                const int is_v = piece >> 4;
-                const int row = (piece & 15) * 4 + p_row;
-                const int chunk = is_v ? ((((p_slot >> 2) ^ (row & 3)) << 2) | (p_slot & 3)) : (p_slot ^ (row & 15));
-                const int key = min(kt0 + row, L - 1);
-                const bf16_t* src = base + (size_t)key * row_stride + d + (size_t)is_v * d + chunk * 8;
-                __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(lds + buf * BUF_BYTES + piece * 1024), 16, 0, 0);
-            }
+            for (int i = 0; i < 32 / NW; ++i) issue_piece(kt0, buf, wave + i * NW);
+        } else {   // short sequences only: a rolled loop keeps the 16-32 source addresses out of registers
+#pragma unroll 1
+            for (int piece = wave; piece < 32; piece += NW) issue_piece(kt0, buf, piece);
         }
     };
     auto write_bias = [&](int kt0, int buf) {
@@ -296,7 +132,6 @@ attn_bidir_dma_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict_
                 const bf16x8 kf = *(const bf16x8*)(k_lds + kb * 32 * 256 + k_row_off + ((ds * 32) ^ k_xor));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
             }
-            if (ds & 1) __builtin_amdgcn_sched_barrier(0);   // at most four K fragments in flight
         }
         // The additive key bias is 0 or -inf, so it can be added before the scaling; the scale and the
         // running max are then folded into one FMA per score: p = 2^(s * scale - m).
@@ -353,9 +188,6 @@ attn_bidir_dma_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict_
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pb[kb][ss], o[db],
                                                                     0, 0, 0);
                 }
-                // keep only one group of V fragments (16 registers) live: hoisting all 32 reads to
-                // the top of the product costs ~50 registers and with them a workgroup per CU
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -379,13 +211,13 @@ attn_bidir_dma_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict_
 }
 
 template <int NW>
-void launch_dma(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* out, int n_seq, int L, int H, int d, float scale,
-                hipStream_t stream) {
+void launch_attn(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* out, int n_seq, int L, int H, int d, float scale,
+                 hipStream_t stream) {
     dim3 grid((L + NW * 32 - 1) / (NW * 32), H, n_seq);
-    hipLaunchKernelGGL((attn_bidir_dma_kernel<NW>), grid, dim3(NW * 64), 0, stream, qkv, key_mask, out, L, d, scale);
+    hipLaunchKernelGGL((attn_bidir_kernel<NW>), grid, dim3(NW * 64), 0, stream, qkv, key_mask, out, L, d, scale);
 }
 
-int g_attn_variant = -1;   // test hook: -1 automatic, 0 register-staged kernel, else waves per workgroup
+int g_attn_variant = 0;   // test hook: waves per workgroup (1, 2, 4), 0 = automatic
 
 }  // namespace
 
@@ -398,29 +230,18 @@ extern "C" int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, v
     LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
     const int d = n_heads * HD;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
-    // Waves per workgroup: as many 32-query waves as the sequence has, at most 12 (one workgroup per
-    // (sequence, head) at L <= 384), fewer when that would leave CUs without a workgroup.
+    // Waves per workgroup: 4 (128 queries), fewer for sequences shorter than that.  More waves per
+    // workgroup (up to one workgroup per (sequence, head), K/V fetched once) were measured slower at
+    // every benchmark shape: the per-tile barrier phase-locks the waves that share a SIMD.
     const int q_waves = (seq_len + 31) / 32;
-    int nw = g_attn_variant;
-    if (nw < 0) {
-        const int groups = (q_waves + 11) / 12;
-        nw = (q_waves + groups - 1) / groups;
-        nw = nw > 8 ? 12 : (nw > 4 ? 8 : (nw > 2 ? 4 : (nw > 1 ? 2 : 1)));
-        while (nw > 2 && (long long)n_seq * n_heads * ((q_waves + nw - 1) / nw) < 256) nw = nw == 12 ? 8 : nw / 2;
-    }
+    const int nw = g_attn_variant > 0 ? g_attn_variant : (q_waves >= 4 ? 4 : (q_waves >= 2 ? 2 : 1));
     const bf16_t* qp = (const bf16_t*)qkv;
     bf16_t* op = (bf16_t*)out;
     hipStream_t st = (hipStream_t)stream;
     switch (nw) {
-        case 12: launch_dma<12>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        case 8: launch_dma<8>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        case 4: launch_dma<4>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        case 2: launch_dma<2>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        case 1: launch_dma<1>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        default: {
-            dim3 grid((seq_len + QB - 1) / QB, n_heads, n_seq);
-            hipLaunchKernelGGL(attn_bidir_kernel, grid, dim3(256), 0, st, qp, key_mask, op, seq_len, d, scale_log2e);
-        }
+        case 4: launch_attn<4>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
+        case 2: launch_attn<2>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
+        default: launch_attn<1>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
     }
     LLADA_CHECK_LAUNCH("attn_bidir_kernel");
     return LLADA_OK;

@@ -272,7 +272,9 @@ def test_gemm_rejects_bad_shapes(lib):
 
 @pytest.mark.parametrize("n_seq,L,H,masked", [(1, 64, 1, False), (2, 100, 2, False), (2, 384, 2, False),
                                              (3, 200, 2, True), (1, 513, 1, True), (2, 31, 1, False)])
-def test_attention(lib, n_seq, L, H, masked):
+@pytest.mark.parametrize("waves", [0, 1, 2, 4])
+def test_attention(lib, n_seq, L, H, masked, waves):
+    """waves = waves per workgroup (0: the library's choice); every variant serves any length."""
     d = H * 128
     g = np.random.Generator(np.random.PCG64(L + H))
     qkv = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
@@ -288,9 +290,13 @@ def test_attention(lib, n_seq, L, H, masked):
     out = torch.full((n_seq * L, d), float("nan"), dtype=torch.bfloat16, device="cuda")
     kmt = None if km is None else dev(km)
     qt = bf(qkv)
-    check(lib, lib.llada_attn_bidir_bf16(qt.data_ptr(), None if kmt is None else kmt.data_ptr(), out.data_ptr(),
-                                         n_seq, L, H, stream()))
-    torch.cuda.synchronize()
+    lib.llada_attn_force_variant(waves)
+    try:
+        check(lib, lib.llada_attn_bidir_bf16(qt.data_ptr(), None if kmt is None else kmt.data_ptr(), out.data_ptr(),
+                                             n_seq, L, H, stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.llada_attn_force_variant(0)
     x = qkv.reshape(n_seq, L, 3, H, 128)
     q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
     ref = omodel.attention(q, k, v, km, False).transpose(0, 2, 1, 3).reshape(n_seq * L, d)
