@@ -70,6 +70,32 @@ def cpu_baseline(B, L, bl, cfg, seconds_hint=20.0):
                            f"{B * bl} rows ({t_head:.2f} s); step = {cfg.n_layers}*layer + head")
 
 
+def measured_ceilings(torch, device, M, N, K):
+    """Yardsticks measured on this GPU next to the vendor peaks: the vendor library's bf16 GEMM
+    (torch.matmul -> hipBLASLt) at the dominant kernel's shape, and a device-to-device copy.
+    Neither is part of the product path."""
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+    a = torch.randn(M, K, device=device).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=device) * 0.02).to(torch.bfloat16)
+    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    t_gemm = timed(lambda: torch.matmul(a, w.t(), out=out), 20)
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    t_copy = timed(lambda: dst.copy_(src), 10)
+    return {"vendor_gemm_tflops": round(2.0 * M * N * K / t_gemm / 1e12, 1), "vendor_gemm_shape": [M, N, K],
+            "memcpy_tb_s": round(2.0 * (1 << 30) / t_copy / 1e12, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +213,7 @@ def main():
                          "launches_timed": n_s.value, "avg_launch_ms": round(gemm_ms, 4),
                          "flops_per_launch": gemm_flops},
         }
+        rec["measured_ceilings"] = measured_ceilings(torch, device, M, 2 * F, d)
         if not args.no_cpu_baseline:
             t_step, cores, sample = cpu_baseline(B, L, bl, cfg)
             rec["cpu_baseline"] = {"value": round(B * G / (steps_total * t_step), 4), "unit": "tokens/s", "cores": cores,
