@@ -46,6 +46,8 @@ extern "C" {
 /* flags of llada_remask_scores */
 #define LLADA_FLAG_LOGITS_EOS_INF 1u       /* generate.py:94-95 */
 #define LLADA_FLAG_CONF_EOS_EOT_INF 2u     /* generate.py:100-101 */
+#define LLADA_FLAG_CONF_FLOAT32 4u         /* confidence = float32 softmax probability, not rounded to bf16:
+                                              eval_llada.py:187 (suffix_greedy_prediction) */
 
 /* GEMM epilogues */
 #define LLADA_EPI_PLAIN 0      /* C = bf16(acc) */

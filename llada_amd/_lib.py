@@ -15,7 +15,7 @@ OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
 
 REMASK = {"low_confidence": 0, "high_confidence": 1, "low_entropy": 2, "high_entropy": 3, "random": 4}
-FLAG_LOGITS_EOS_INF, FLAG_CONF_EOS_EOT_INF = 1, 2
+FLAG_LOGITS_EOS_INF, FLAG_CONF_EOS_EOT_INF, FLAG_CONF_FLOAT32 = 1, 2, 4
 EPI_PLAIN, EPI_RESIDUAL, EPI_ROPE_QKV, EPI_SWIGLU = 0, 1, 2, 3
 
 vp = C.c_void_p

@@ -248,8 +248,9 @@ __global__ void __launch_bounds__(RT) remask_rows_kernel(const llada_remask_args
                 if (x0 == rc.eos_for_logits) c = -INFINITY;
                 lx = softmax_view(rc, x0, c);
             }
-            const float p = round_bf16(expf(lx - m) / s);
-            conf = (a.remasking == LLADA_REMASK_LOW_CONFIDENCE) ? p : round_bf16(1.0f - p);
+            const bool f32 = (a.flags & LLADA_FLAG_CONF_FLOAT32) != 0;   // eval_llada.py:187 softmaxes in float32
+            const float p = f32 ? expf(lx - m) / s : round_bf16(expf(lx - m) / s);
+            conf = (a.remasking == LLADA_REMASK_LOW_CONFIDENCE) ? p : (f32 ? 1.0f - p : round_bf16(1.0f - p));
         } else {
             // ---- pass 3: sum of bf16(log_p * p), both factors rounded to bf16 first ----
             const float lse = logf(s);
