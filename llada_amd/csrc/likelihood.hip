@@ -9,10 +9,9 @@
 //                      p_mask; a second tiny kernel adds the row losses in a fixed order (float64).
 #include "common.h"
 #include "philox.h"
+#include "rowregs.h"
 
 namespace {
-
-constexpr int RT = 512;
 
 __global__ void __launch_bounds__(256) ll_mask_kernel(const int64_t* __restrict__ seq, int64_t* __restrict__ noisy,
                                                       int l, int prompt_len, int64_t mask_id,
@@ -48,21 +47,16 @@ __global__ void __launch_bounds__(256) ll_mask_kernel(const int64_t* __restrict_
     }
 }
 
-__device__ __forceinline__ float cfg_combine(float c, float u, float cfg1) {
-    float d = round_bf16(c - u);
-    d = round_bf16(d * cfg1);
-    return round_bf16(u + d);
-}
-
-__global__ void __launch_bounds__(RT) masked_ce_kernel(const bf16_t* __restrict__ logits,
-                                                       const bf16_t* __restrict__ uncond, float cfg1,
-                                                       const int32_t* __restrict__ row_pos, int V,
-                                                       const int64_t* __restrict__ noisy,
-                                                       const int64_t* __restrict__ seq, int l, int64_t mask_id,
-                                                       const float* __restrict__ p_mask_rows, int round_ce,
-                                                       float* __restrict__ row_loss) {
-    __shared__ float red[RT / 64];
-    __shared__ float bc[2];
+// One 1024-thread workgroup per row; the row is read from memory once and kept on chip (rowregs.h).
+__global__ void __launch_bounds__(ROW_THREADS) masked_ce_kernel(const bf16_t* __restrict__ logits,
+                                                                const bf16_t* __restrict__ uncond, float cfg1,
+                                                                const int32_t* __restrict__ row_pos, int V,
+                                                                const int64_t* __restrict__ noisy,
+                                                                const int64_t* __restrict__ seq, int l, int64_t mask_id,
+                                                                const float* __restrict__ p_mask_rows, int round_ce,
+                                                                float* __restrict__ row_loss) {
+    __shared__ float red[2][ROW_THREADS / 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];   // ROW_LDS_BYTES
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pos = row_pos ? row_pos[r] : r;
     if (noisy[pos] != mask_id) {
@@ -71,49 +65,11 @@ __global__ void __launch_bounds__(RT) masked_ce_kernel(const bf16_t* __restrict_
     }
     const bf16_t* lc = logits + (size_t)r * V;
     const bf16_t* lu = uncond ? uncond + (size_t)r * V : nullptr;
-    const int chunks = V / 8;
-    auto load = [&](int c, float (&v)[8]) {
-        const u16x8 a = *(const u16x8*)(lc + (size_t)c * 8);
-        if (lu) {
-            const u16x8 u = *(const u16x8*)(lu + (size_t)c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = cfg_combine(bf16_to_f32(a[e]), bf16_to_f32(u[e]), cfg1);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32(a[e]);
-        }
-    };
-    float mx = -INFINITY;
-    for (int c = tid; c < chunks; c += RT) {
-        float v[8];
-        load(c, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
-    }
-    mx = wave_reduce_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
+    RowRegs row;
+    row.load(lc, lu, cfg1, V / 8, tid, row_lds);
+    const float m = block_max16(row.max(), red[0], lane, wave);
+    const float tot = block_sum16(row.sum_exp(m), red[1], lane, wave);
     if (tid == 0) {
-        float m = red[0];
-        for (int w = 1; w < RT / 64; ++w) m = fmaxf(m, red[w]);
-        bc[0] = m;
-    }
-    __syncthreads();
-    const float m = bc[0];
-    float s = 0.f;
-    for (int c = tid; c < chunks; c += RT) {
-        float v[8];
-        load(c, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += expf(v[e] - m);
-    }
-    s = wave_reduce_sum(s);
-    __syncthreads();
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    if (tid == 0) {
-        float tot = 0.f;
-        for (int w = 0; w < RT / 64; ++w) tot += red[w];
         const int64_t tgt = seq[pos];
         float lt = bf16_to_f32(lc[tgt]);
         if (lu) lt = cfg_combine(lt, bf16_to_f32(lu[tgt]), cfg1);
@@ -160,9 +116,20 @@ extern "C" int llada_masked_ce(const void* logits, const void* uncond_logits, do
     LLADA_CHECK_ARG(logits && noisy && seq && p_mask_rows && row_loss && loss_sum, "masked_ce: null tensor");
     LLADA_CHECK_ARG(n_rows > 0 && vocab > 0 && b > 0 && l > 0, "masked_ce: bad shape");
     LLADA_CHECK_SUPPORTED(vocab % 8 == 0, "masked_ce: vocab=%d must be a multiple of 8", vocab);
+    LLADA_CHECK_SUPPORTED(vocab <= ROW_MAX_VOCAB, "masked_ce: vocab=%d exceeds %d (one row must fit on chip)", vocab, ROW_MAX_VOCAB);
     LLADA_CHECK_ARG(row_pos != nullptr || n_rows == b * l, "masked_ce: row_pos is required unless n_rows == b*l");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(masked_ce_kernel, dim3(n_rows), dim3(RT), 0, s, (const bf16_t*)logits,
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)masked_ce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           ROW_LDS_BYTES);
+        if (e != hipSuccess) {
+            llada_set_error("hipFuncSetAttribute(masked_ce_kernel): %s", hipGetErrorString(e));
+            return LLADA_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(masked_ce_kernel, dim3(n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, (const bf16_t*)logits,
                        (const bf16_t*)uncond_logits, (float)(cfg_scale + 1.0), row_pos, vocab, noisy, seq, l, mask_id,
                        p_mask_rows, round_ce_bf16, row_loss);
     LLADA_CHECK_LAUNCH("masked_ce_kernel");

@@ -10,10 +10,9 @@
 //   num_transfer_kernel : get_num_transfer_tokens (:22-40) on the block slice (:75-79).
 #include "common.h"
 #include "philox.h"
+#include "rowregs.h"
 
 namespace {
-
-constexpr int RT = 512;  // threads per logits row
 
 struct ArgD {
     double v;
@@ -42,43 +41,6 @@ __device__ __forceinline__ A wave_argmax(A a) {
     return a;
 }
 
-struct RowCtx {
-    const bf16_t* lc;  // conditional logits row
-    const bf16_t* lu;  // unconditional logits row or nullptr
-    float cfg1;        // cfg_scale + 1
-    int eos_for_logits;   // vocab id forced to -inf before sampling, or -1
-    int sm_excl0, sm_excl1;  // vocab ids excluded from the softmax (set to -inf after x0 is taken), or -1
-};
-
-// generate.py:89-90 on one element, each op rounding to bf16 as torch does on bf16 tensors
-__device__ __forceinline__ float cfg_combine(float c, float u, float cfg1) {
-    float d = round_bf16(c - u);
-    d = round_bf16(d * cfg1);
-    return round_bf16(u + d);
-}
-
-__device__ __forceinline__ void load_chunk(const RowCtx& rc, int chunk, float (&l)[8]) {
-    const u16x8 c = *(const u16x8*)(rc.lc + (size_t)chunk * 8);
-    if (rc.lu) {
-        const u16x8 u = *(const u16x8*)(rc.lu + (size_t)chunk * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) l[e] = cfg_combine(bf16_to_f32(c[e]), bf16_to_f32(u[e]), rc.cfg1);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) l[e] = bf16_to_f32(c[e]);
-    }
-    const int v0 = chunk * 8;
-    if (rc.eos_for_logits >= v0 && rc.eos_for_logits < v0 + 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (v0 + e == rc.eos_for_logits) l[e] = -INFINITY;
-    }
-}
-
-__device__ __forceinline__ float softmax_view(const RowCtx& rc, int v, float l) {
-    return (v == rc.sm_excl0 || v == rc.sm_excl1) ? -INFINITY : l;
-}
-
 __global__ void remask_default_kernel(const int64_t* __restrict__ x, int64_t* __restrict__ x0,
                                       float* __restrict__ conf, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -87,13 +49,15 @@ __global__ void remask_default_kernel(const int64_t* __restrict__ x, int64_t* __
     }
 }
 
+// One 1024-thread workgroup per logits row; the row is read from memory once into registers
+// (rowregs.h) and every sweep below runs on them.
 template <bool GUMBEL>
-__global__ void __launch_bounds__(RT) remask_rows_kernel(const llada_remask_args a) {
-    __shared__ float red_f[RT / 64];
-    __shared__ int red_i[RT / 64];
-    __shared__ double red_d[RT / 64];
-    __shared__ float bc_f[2];
-    __shared__ int bc_i;
+__global__ void __launch_bounds__(ROW_THREADS) remask_rows_kernel(const llada_remask_args a) {
+    constexpr int NW = ROW_THREADS / 64;
+    __shared__ float red_f[3][NW];
+    __shared__ int red_i[NW];
+    __shared__ double red_d[NW];
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];   // ROW_LDS_BYTES
 
     const int r = blockIdx.x;
     const int pos = a.row_pos ? a.row_pos[r] : r;
@@ -102,32 +66,39 @@ __global__ void __launch_bounds__(RT) remask_rows_kernel(const llada_remask_args
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = a.vocab, chunks = V / 8;
-    RowCtx rc;
-    rc.lc = (const bf16_t*)a.logits + (size_t)r * V;
-    rc.lu = a.uncond_logits ? (const bf16_t*)a.uncond_logits + (size_t)r * V : nullptr;
-    rc.cfg1 = (float)(a.cfg_scale + 1.0);
-    rc.eos_for_logits = (a.flags & LLADA_FLAG_LOGITS_EOS_INF) ? a.eos_id : -1;
-    rc.sm_excl0 = rc.sm_excl1 = -1;
-    if (a.flags & LLADA_FLAG_CONF_EOS_EOT_INF) {
-        // generate.py:101 `logits_with_noise[..EOS] = logits[..EoT] = -inf`: at temperature 0 both
-        // names are one tensor, so the softmax loses EOS and EoT; otherwise only EoT.
-        rc.sm_excl0 = a.eot_id;
-        if (!GUMBEL) rc.sm_excl1 = a.eos_id;
-    }
-    const bool need_softmax = a.remasking != LLADA_REMASK_RANDOM;
+    const bf16_t* lc = (const bf16_t*)a.logits + (size_t)r * V;
+    const bf16_t* lu = a.uncond_logits ? (const bf16_t*)a.uncond_logits + (size_t)r * V : nullptr;
+    const float cfg1 = (float)(a.cfg_scale + 1.0);
 
-    // ---- pass 1: argmax (float64 Gumbel-max when sampling) and the softmax maximum ----
-    float smax = -INFINITY;
-    ArgF bf = {-INFINITY, 0x7fffffff};
-    ArgD bd = {-1.0, 0x7fffffff};
-    uint32_t k0 = 0, k1 = 0;
-    if (GUMBEL) philox_key(a.seed, LLADA_STREAM_GUMBEL, k0, k1);
-    const double temp = (double)a.temperature;
-    for (int c = tid; c < chunks; c += RT) {
-        float l[8];
-        load_chunk(rc, c, l);
-        double u[8];
-        if (GUMBEL) {
+    RowRegs row;
+    const bool eos_inf = (a.flags & LLADA_FLAG_LOGITS_EOS_INF) != 0;                 // generate.py:94-95
+    if (!GUMBEL) {
+        row.load(lc, lu, cfg1, chunks, tid, row_lds);
+        if (eos_inf) row.exclude(a.eos_id, tid);
+    }
+
+    // ---- sweep 1: argmax (float64 Gumbel-max when sampling, generate.py:16-19,98) ----
+    int x0;
+    float best_logit = 0.f;   // T == 0: the winning logit = the softmax maximum when nothing is excluded
+    if (GUMBEL) {
+        // The float64 pow/log/exp per entry dominate this sweep and need the registers, so it streams
+        // the row from memory; the register copy for the softmax sweeps is loaded afterwards (from
+        // the cache hierarchy).
+        ArgD bd = {-(double)INFINITY, 0x7fffffff};
+        uint32_t k0, k1;
+        philox_key(a.seed, LLADA_STREAM_GUMBEL, k0, k1);
+        const double temp = (double)a.temperature;
+#pragma unroll 1
+        for (int c = tid; c < chunks; c += ROW_THREADS) {
+            u32x4 qv = *(const u32x4*)(lc + (size_t)c * 8);
+            if (lu) {
+                const u32x4 uv = *(const u32x4*)(lu + (size_t)c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    qv[e] = pack_bf16x2(cfg_combine(bf16lo(qv[e]), bf16lo(uv[e]), cfg1),
+                                        cfg_combine(bf16hi(qv[e]), bf16hi(uv[e]), cfg1));
+            }
+            double u[8];
             if (a.noise) {
                 const double* np = a.noise + (size_t)r * V + (size_t)c * 8;
 #pragma unroll
@@ -141,76 +112,66 @@ __global__ void __launch_bounds__(RT) remask_rows_kernel(const llada_remask_args
                     u[2 * h2 + 1] = u53(ph.v[2], ph.v[3]);
                 }
             }
-        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int v = c * 8 + e;
-            if (GUMBEL) {
-                // generate.py:16-19: exp(logits) / (-log u) ** T, all float64
-                const double g = pow(-log(u[e]), temp);
-                const double sc = exp((double)l[e]) / g;
+            for (int e = 0; e < 8; ++e) {
+                const int v = c * 8 + e;
+                float l = (e & 1) ? bf16hi(qv[e >> 1]) : bf16lo(qv[e >> 1]);
+                if (eos_inf && v == a.eos_id) l = -INFINITY;
+                // generate.py:16-19 ranks exp(logits) / (-log u) ** T in float64; its logarithm
+                // l - T * log(-log u) has the same arg-max and needs two logarithms instead of a
+                // pow, an exp and a division (this sweep is bound by float64 arithmetic)
+                const double sc = (double)l - temp * log(-log(u[e]));
                 if (sc > bd.v || (sc == bd.v && v < bd.i)) {
                     bd.v = sc;
                     bd.i = v;
                 }
-            } else {
-                if (l[e] > bf.v || (l[e] == bf.v && v < bf.i)) {
-                    bf.v = l[e];
-                    bf.i = v;
-                }
             }
-            smax = fmaxf(smax, softmax_view(rc, v, l[e]));
         }
-    }
-    int x0;
-    if (GUMBEL) {
         bd = wave_argmax(bd);
         if (lane == 0) {
             red_d[wave] = bd.v;
             red_i[wave] = bd.i;
         }
+        __syncthreads();
+        bd.v = red_d[0];
+        bd.i = red_i[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) bd = arg_better(bd, ArgD{red_d[w], red_i[w]});
+        x0 = bd.i;
+        row.load(lc, lu, cfg1, chunks, tid, row_lds);
+        if (eos_inf) row.exclude(a.eos_id, tid);
     } else {
+        ArgF bf = {-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int i = 0; i < ROW_SLOTS; ++i) {
+            const int v0 = (tid + i * ROW_THREADS) * 8;   // ascending within a lane: '>' keeps the first maximum
+            const u32x4 t = row.get(i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float l = (e & 1) ? bf16hi(t[e >> 1]) : bf16lo(t[e >> 1]);
+                if (l > bf.v) {
+                    bf.v = l;
+                    bf.i = v0 + e;
+                }
+            }
+        }
+        if (bf.i == 0x7fffffff) bf.i = tid * 8;           // a lane that saw only -inf: its first entry
         bf = wave_argmax(bf);
         if (lane == 0) {
-            red_f[wave] = bf.v;
+            red_f[0][wave] = bf.v;
             red_i[wave] = bf.i;
         }
+        __syncthreads();
+        bf.v = red_f[0][0];
+        bf.i = red_i[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) bf = arg_better(bf, ArgF{red_f[0][w], red_i[w]});
+        x0 = bf.i;
+        best_logit = bf.v;
     }
-    __syncthreads();
-    if (tid == 0) {
-        int bi = red_i[0];
-        if (GUMBEL) {
-            double bv = red_d[0];
-            for (int w = 1; w < RT / 64; ++w)
-                if (red_d[w] > bv || (red_d[w] == bv && red_i[w] < bi)) {
-                    bv = red_d[w];
-                    bi = red_i[w];
-                }
-        } else {
-            float bv = red_f[0];
-            for (int w = 1; w < RT / 64; ++w)
-                if (red_f[w] > bv || (red_f[w] == bv && red_i[w] < bi)) {
-                    bv = red_f[w];
-                    bi = red_i[w];
-                }
-        }
-        bc_i = bi;
-    }
-    __syncthreads();
-    x0 = bc_i;
-    smax = wave_reduce_max(smax);
-    if (lane == 0) red_f[wave] = smax;
-    __syncthreads();
-    if (tid == 0) {
-        float m = red_f[0];
-        for (int w = 1; w < RT / 64; ++w) m = fmaxf(m, red_f[w]);
-        bc_f[0] = m;
-    }
-    __syncthreads();
-    const float m = bc_f[0];
 
     float conf;
-    if (!need_softmax) {
+    if (a.remasking == LLADA_REMASK_RANDOM) {
         if (a.rand_scores) {
             conf = a.rand_scores[pos];
         } else {
@@ -220,59 +181,50 @@ __global__ void __launch_bounds__(RT) remask_rows_kernel(const llada_remask_args
             conf = (float)(ph.v[0] >> 8) * (1.0f / 16777216.0f);
         }
     } else {
-        // ---- pass 2: sum of exp(l - max) ----
-        float ssum = 0.f;
-        for (int c = tid; c < chunks; c += RT) {
-            float l[8];
-            load_chunk(rc, c, l);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ssum += expf(softmax_view(rc, c * 8 + e, l[e]) - m);
+        // generate.py:101 `logits_with_noise[..EOS] = logits[..EoT] = -inf` after x0 is taken: at
+        // temperature 0 both names are one tensor, so the softmax loses EOS and EoT; otherwise only EoT.
+        int excl0 = -1, excl1 = -1;
+        if (a.flags & LLADA_FLAG_CONF_EOS_EOT_INF) {
+            excl0 = a.eot_id;
+            if (!GUMBEL) excl1 = a.eos_id;
+            row.exclude(excl0, tid);
+            row.exclude(excl1, tid);
         }
-        ssum = wave_reduce_sum(ssum);
-        __syncthreads();
-        if (lane == 0) red_f[wave] = ssum;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int w = 0; w < RT / 64; ++w) s += red_f[w];
-            bc_f[1] = s;
-        }
-        __syncthreads();
-        const float s = bc_f[1];
+        // ---- sweep 2: softmax maximum (known already at temperature 0 without exclusions) ----
+        float m;
+        if (!GUMBEL && excl0 < 0)
+            m = best_logit;
+        else
+            m = block_max16(row.max(), red_f[1], lane, wave);
+        // ---- sweep 3: sum of exp(l - max) ----
+        const float s = block_sum16(row.sum_exp(m), red_f[2], lane, wave);
         if (a.remasking == LLADA_REMASK_LOW_CONFIDENCE || a.remasking == LLADA_REMASK_HIGH_CONFIDENCE) {
             // p[x0], rounded to bf16 like F.softmax on a bf16 tensor
-            float lx;
-            {
-                float c = bf16_to_f32(rc.lc[x0]);
-                if (rc.lu) c = cfg_combine(c, bf16_to_f32(rc.lu[x0]), rc.cfg1);
-                if (x0 == rc.eos_for_logits) c = -INFINITY;
-                lx = softmax_view(rc, x0, c);
-            }
+            float lx = bf16_to_f32(lc[x0]);
+            if (lu) lx = cfg_combine(lx, bf16_to_f32(lu[x0]), cfg1);
+            if (((a.flags & LLADA_FLAG_LOGITS_EOS_INF) && x0 == a.eos_id) || x0 == excl0 || x0 == excl1) lx = -INFINITY;
             const bool f32 = (a.flags & LLADA_FLAG_CONF_FLOAT32) != 0;   // eval_llada.py:187 softmaxes in float32
             const float p = f32 ? expf(lx - m) / s : round_bf16(expf(lx - m) / s);
             conf = (a.remasking == LLADA_REMASK_LOW_CONFIDENCE) ? p : (f32 ? 1.0f - p : round_bf16(1.0f - p));
         } else {
-            // ---- pass 3: sum of bf16(log_p * p), both factors rounded to bf16 first ----
-            const float lse = logf(s);
+            // ---- sweep 4: sum of bf16(log_p * p), both factors rounded to bf16 first ----
+            const float lse = logf(s), inv_s = 1.0f / s;
             float esum = 0.f;
-            for (int c = tid; c < chunks; c += RT) {
-                float l[8];
-                load_chunk(rc, c, l);
+#pragma unroll
+            for (int i = 0; i < ROW_SLOTS; ++i) {
+                if (tid + i * ROW_THREADS >= chunks) continue;
+                const u32x4 t = row.get(i);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float z = softmax_view(rc, c * 8 + e, l[e]) - m;
-                    const float p = round_bf16(expf(z) / s);
+                    const float l = (e & 1) ? bf16hi(t[e >> 1]) : bf16lo(t[e >> 1]);
+                    const float z = l - m;
+                    const float p = round_bf16(__expf(z) * inv_s);
                     const float lp = round_bf16(z - lse);
                     esum += round_bf16(lp * p);
                 }
             }
-            esum = wave_reduce_sum(esum);
-            __syncthreads();
-            if (lane == 0) red_f[wave] = esum;
-            __syncthreads();
-            float tot = 0.f;
-            for (int w = 0; w < RT / 64; ++w) tot += red_f[w];
-            tot = round_bf16(tot);
+            __syncthreads();   // red_f[1] may still be read by the maximum above
+            const float tot = round_bf16(block_sum16(esum, red_f[1], lane, wave));
             conf = (a.remasking == LLADA_REMASK_LOW_ENTROPY) ? -tot : tot;
         }
     }
@@ -360,6 +312,7 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
     LLADA_CHECK_ARG(a.logits && a.x && a.x0 && a.confidence, "remask_scores: null tensor");
     LLADA_CHECK_ARG(a.n_rows > 0 && a.B > 0 && a.L > 0 && a.vocab > 0, "remask_scores: bad shape");
     LLADA_CHECK_SUPPORTED(a.vocab % 8 == 0, "remask_scores: vocab=%d must be a multiple of 8", a.vocab);
+    LLADA_CHECK_SUPPORTED(a.vocab <= ROW_MAX_VOCAB, "remask_scores: vocab=%d exceeds %d (one row must fit the registers of a workgroup)", a.vocab, ROW_MAX_VOCAB);
     LLADA_CHECK_ARG(a.row_pos != nullptr || a.n_rows == a.B * a.L, "remask_scores: row_pos is required unless n_rows == B*L");
     if (a.remasking < LLADA_REMASK_LOW_CONFIDENCE || a.remasking > LLADA_REMASK_RANDOM) {
         llada_set_error("remask_scores: unknown remasking rule %d", a.remasking);
@@ -373,10 +326,22 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
     const int g = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(remask_default_kernel, dim3(g), dim3(256), 0, s, a.x, a.x0, a.confidence, n);
     LLADA_CHECK_LAUNCH("remask_default_kernel");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)remask_rows_kernel<true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, ROW_LDS_BYTES);
+        hipError_t e2 = hipFuncSetAttribute((const void*)remask_rows_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, ROW_LDS_BYTES);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            llada_set_error("hipFuncSetAttribute(remask_rows_kernel): %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            return LLADA_ERR_HIP;
+        }
+        attr_set = true;
+    }
     if (a.temperature != 0.0f)
-        hipLaunchKernelGGL(remask_rows_kernel<true>, dim3(a.n_rows), dim3(RT), 0, s, a);
+        hipLaunchKernelGGL(remask_rows_kernel<true>, dim3(a.n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, a);
     else
-        hipLaunchKernelGGL(remask_rows_kernel<false>, dim3(a.n_rows), dim3(RT), 0, s, a);
+        hipLaunchKernelGGL(remask_rows_kernel<false>, dim3(a.n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, a);
     LLADA_CHECK_LAUNCH("remask_rows_kernel");
     return LLADA_OK;
 }
