@@ -96,6 +96,65 @@ def measured_ceilings(torch, device, M, N, K):
             "memcpy_tb_s": round(2.0 * (1 << 30) / t_copy / 1e12, 2)}
 
 
+def timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all, on_start=None, row_offset=0):
+    """Runs generate() (steps == gen_length) and times steps W_ .. W_+K_ of it between two
+    barrier + synchronize pairs; returns seconds for the K_ steps."""
+    state = {"n": 0, "t0": None, "t1": None}
+
+    def begin():
+        sync_all()
+        if on_start is not None:
+            on_start()
+        state["t0"] = time.perf_counter()
+
+    def cb(block, step, x, x0, conf):
+        state["n"] += 1
+        if state["n"] == W_:
+            begin()
+        elif state["n"] == W_ + K_:
+            sync_all()
+            state["t1"] = time.perf_counter()
+
+    if W_ == 0:
+        begin()
+    while state["t1"] is None:
+        generate(model, prompt, None, steps=G, gen_length=G, block_length=bl, temperature=0., cfg_scale=0.,
+                 remasking="low_confidence", row_offset=row_offset, step_callback=cb)
+    return state["t1"] - state["t0"]
+
+
+def epilogue_roofline(torch, lib, _lib, device, rows, V, mask_id):
+    """The fused remasking epilogue alone (HBM-bound): `rows` full-vocabulary logits rows per launch,
+    timed with events on the launch stream over a ring of buffers larger than the caches."""
+    n_ring = 8
+    ring = [torch.randn(rows, V, device=device).mul_(3).to(torch.bfloat16) for _ in range(n_ring)]
+    x = torch.full((1, rows), mask_id, dtype=torch.long, device=device)
+    x0 = torch.empty_like(x)
+    conf = torch.empty((1, rows), dtype=torch.float32, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(i):
+        a = _lib.RemaskArgs(ring[i % n_ring].data_ptr(), None, 0.0, None, rows, V, x.data_ptr(), 1, rows, rows, mask_id,
+                            _lib.REMASK["low_confidence"], 0, 126081, 126348, 0.0, None, None, 0, 0, 0, x0.data_ptr(),
+                            conf.data_ptr())
+        _lib.check(lib.llada_remask_scores(C.byref(a), st))
+    for i in range(4):
+        call(i)
+    torch.cuda.synchronize()
+    n = 32
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        call(i)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / n * 1e-3
+    nbytes = rows * V * 2
+    return {"bound": "hbm", "kernel": "remask_rows_kernel<false> (+ the defaults kernel it follows), low_confidence, temperature 0",
+            "achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
+            "rows_per_launch": rows, "bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 2), "traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +166,7 @@ def main():
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers makes the result INVALID")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency leg")
     args = ap.parse_args()
 
     import torch
@@ -142,7 +202,6 @@ def main():
     prompt = prompts_all[rank * B:(rank + 1) * B]
 
     W_, K_ = args.warmup, args.steps
-    state = {"n": 0, "t0": None, "t1": None}
 
     def sync_all():
         torch.cuda.synchronize()
@@ -150,28 +209,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def cb(block, step, x, x0, conf):
-        state["n"] += 1
-        if state["n"] == W_:
-            sync_all()
-            lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L)
-            state["t0"] = time.perf_counter()
-        elif state["n"] == W_ + K_:
-            sync_all()
-            state["t1"] = time.perf_counter()
-
-    if W_ == 0:
-        sync_all()
-        lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L)
-        state["t0"] = time.perf_counter()
-    out = None
-    while state["t1"] is None:
-        out = generate(model, prompt, None, steps=steps_total, gen_length=G, block_length=bl, temperature=0.,
-                       cfg_scale=0., remasking="low_confidence", row_offset=rank * B, step_callback=cb)
+    elapsed = timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all,
+                          on_start=lambda: lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L),
+                          row_offset=rank * B)
     tot_ms, n_s = C.c_double(0), C.c_int(0)
     lib.llada_gemm_profile_end(C.byref(tot_ms), C.byref(n_s))
     torch.cuda.synchronize()
-    elapsed = state["t1"] - state["t0"]
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -214,6 +257,13 @@ def main():
                          "flops_per_launch": gemm_flops},
         }
         rec["measured_ceilings"] = measured_ceilings(torch, device, M, 2 * F, d)
+        rec["epilogue_roofline"] = epilogue_roofline(torch, lib, _lib, device, R, V, cfg.mask_token_id)
+        if world == 1 and B != 1 and not args.no_latency:
+            # the single-sequence configuration (batch 1, same gen_length / steps / block_length):
+            # per-step latency of forward + epilogue
+            t1 = timed_steps(generate, model, prompt[:1], G, bl, W_, K_, sync_all)
+            rec["latency_batch1"] = {"ms_per_step": round(1e3 * t1 / K_, 4), "tokens_per_s": round(G / (steps_total * t1 / K_), 2),
+                                     "workload": f"1 prompt x P={P}, gen_length={G}, steps={steps_total}, block_length={bl}"}
         if not args.no_cpu_baseline:
             t_step, cores, sample = cpu_baseline(B, L, bl, cfg)
             rec["cpu_baseline"] = {"value": round(B * G / (steps_total * t_step), 4), "unit": "tokens/s", "cores": cores,
