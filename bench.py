@@ -264,7 +264,7 @@ def main():
             t1 = timed_steps(generate, model, prompt[:1], G, bl, W_, K_, sync_all)
             rec["latency_batch1"] = {"ms_per_step": round(1e3 * t1 / K_, 4), "tokens_per_s": round(G / (steps_total * t1 / K_), 2),
                                      "workload": f"1 prompt x P={P}, gen_length={G}, steps={steps_total}, block_length={bl}"}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # the host baseline is reported at N = 1 only
             t_step, cores, sample = cpu_baseline(B, L, bl, cfg)
             rec["cpu_baseline"] = {"value": round(B * G / (steps_total * t_step), 4), "unit": "tokens/s", "cores": cores,
                                    "kind": "port", "sample": sample, "ms_per_step": round(1e3 * t_step, 1)}
