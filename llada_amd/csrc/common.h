@@ -48,6 +48,20 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     return v;
 }
 
+// Per-device "done once" flag for function attributes (hipFuncSetAttribute applies to the current
+// device only): true the first time it is asked on a device.
+struct OncePerDevice {
+    bool done[64] = {};
+    bool first() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) return true;
+        const bool f = !done[dev];
+        done[dev] = true;
+        return f;
+    }
+};
+
 // ---- host side error plumbing -------------------------------------------------------------
 void llada_set_error(const char* fmt, ...);
 

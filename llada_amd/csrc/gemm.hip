@@ -854,15 +854,14 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
                                (g_use_pipelined == 1 && EPI == LLADA_EPI_SWIGLU && grid >= 2 * g_stream_grid);
         if (stream_ok && nk >= 4 && (nk & 1) == 0) {
             constexpr int stream_lds = lds + 8 * 2 * 16 * 144;   // + the write-out slices (2 m-fragments per wave)
-            static bool attr3_set = false;
-            if (!attr3_set) {
+            static OncePerDevice attr3_set;
+            if (attr3_set.first()) {
                 hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_stream_kernel<MFR, EPI>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, stream_lds);
                 if (e != hipSuccess) {
                     llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
                     return LLADA_ERR_HIP;
                 }
-                attr3_set = true;
             }
             const int sgrid = grid < g_stream_grid ? grid : g_stream_grid;
             hipLaunchKernelGGL((gemm_bf16_stream_kernel<MFR, EPI>), dim3(sgrid), dim3(NTHREADS), stream_lds, stream, q);
@@ -870,30 +869,28 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
             return LLADA_OK;
         }
         if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
-            static bool attr2_set = false;
-            if (!attr2_set) {
+            static OncePerDevice attr2_set;
+            if (attr2_set.first()) {
                 hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) {
                     llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
                     return LLADA_ERR_HIP;
                 }
-                attr2_set = true;
             }
             hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
             LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
             return LLADA_OK;
         }
     }
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static OncePerDevice attr_set;
+    if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<MFR, EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
             return LLADA_ERR_HIP;
         }
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
     LLADA_CHECK_LAUNCH("gemm_bf16_kernel");

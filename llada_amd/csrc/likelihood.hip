@@ -119,15 +119,14 @@ extern "C" int llada_masked_ce(const void* logits, const void* uncond_logits, do
     LLADA_CHECK_SUPPORTED(vocab <= ROW_MAX_VOCAB, "masked_ce: vocab=%d exceeds %d (one row must fit on chip)", vocab, ROW_MAX_VOCAB);
     LLADA_CHECK_ARG(row_pos != nullptr || n_rows == b * l, "masked_ce: row_pos is required unless n_rows == b*l");
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_set;
+    if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)masked_ce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            ROW_LDS_BYTES);
         if (e != hipSuccess) {
             llada_set_error("hipFuncSetAttribute(masked_ce_kernel): %s", hipGetErrorString(e));
             return LLADA_ERR_HIP;
         }
-        attr_set = true;
     }
     hipLaunchKernelGGL(masked_ce_kernel, dim3(n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, (const bf16_t*)logits,
                        (const bf16_t*)uncond_logits, (float)(cfg_scale + 1.0), row_pos, vocab, noisy, seq, l, mask_id,

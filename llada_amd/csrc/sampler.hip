@@ -326,8 +326,8 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
     const int g = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(remask_default_kernel, dim3(g), dim3(256), 0, s, a.x, a.x0, a.confidence, n);
     LLADA_CHECK_LAUNCH("remask_default_kernel");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_set;
+    if (attr_set.first()) {
         hipError_t e1 = hipFuncSetAttribute((const void*)remask_rows_kernel<true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, ROW_LDS_BYTES);
         hipError_t e2 = hipFuncSetAttribute((const void*)remask_rows_kernel<false>,
@@ -336,7 +336,6 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
             llada_set_error("hipFuncSetAttribute(remask_rows_kernel): %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             return LLADA_ERR_HIP;
         }
-        attr_set = true;
     }
     if (a.temperature != 0.0f)
         hipLaunchKernelGGL(remask_rows_kernel<true>, dim3(a.n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, a);
