@@ -141,6 +141,15 @@ int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int32_t N,
                     void* stream);
 size_t llada_gemm_workspace_bytes(int64_t M, int32_t N, int32_t K);
 
+/* X[M, N] += A[M, K] @ W[N, K]^T (bf16 residual stream, in place, row stride N) and
+ * H[M, N] = RMSNorm(X) * norm_w: a residual projection of the mask predictor (attn_out or ff_out, called at
+ * generate.py:88,92 / get_log_likelihood.py:38) together with the norm that reads its result.  Bit-identical
+ * to llada_gemm_bf16(EPI_RESIDUAL) followed by llada_rmsnorm_bf16; when the GEMM runs split-K (small M) the
+ * second pass writes both outputs, which saves a kernel and a round trip of the residual stream. */
+int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, void* X, void* H, const void* norm_w, float eps,
+                                     int64_t M, int32_t N, int32_t K, int32_t lda, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+
 /* In-place rotary embedding of the Q and K thirds of qkv [n_seq*seq_len, 3*d] (natural head
  * layout, pairs (j, j+64)); float32 arithmetic, bf16 result. */
 int llada_rope_bf16(void* qkv, const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "llada_embed_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_gather_rows_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp, vp]),
+    "llada_gemm_residual_rmsnorm_bf16": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, C.c_int32,
+                                                   C.c_int32, vp, C.c_size_t, vp]),
     "llada_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
                                   C.c_int32, vp, vp, C.c_int32, vp, C.c_size_t, vp]),
     "llada_gemm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

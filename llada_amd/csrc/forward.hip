@@ -97,8 +97,13 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     void* hc = (unsigned char*)qkv + (size_t)R * d * 2; // [R, d] its norm
 
     TRY(llada_embed_bf16(w->wte, ids, x, M, d, V, stream));
+    // Every residual projection is issued together with the norm that reads its result (the output
+    // projection with ff_norm, the down projection with the next layer's attn_norm or the final norm):
+    // llada_gemm_residual_rmsnorm_bf16 folds the norm into the GEMM's second pass when it has one.
+    if (c.n_layers > 0) TRY(llada_rmsnorm_bf16(x, w->attn_norm[0], h, M, d, c.rms_eps, nullptr, stream));
+    bool final_norm_done = false;
     for (int l = 0; l < c.n_layers; ++l) {
-        TRY(llada_rmsnorm_bf16(x, w->attn_norm[l], h, M, d, c.rms_eps, nullptr, stream));
+        const bool last = l == c.n_layers - 1;
         if (w->packed) {
             TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, rope_cos,
                                 rope_sin, seq_len, sk, skb, stream));
@@ -112,7 +117,7 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
         void* xl = x;        // residual stream of those rows
         void* al = att;      // attention output of those rows
         void* hl = h;
-        if (prune && l == c.n_layers - 1) {
+        if (prune && last) {
             TRY(llada_gather_rows_bf16(att, logit_rows, h, R, d, M, stream));   // h is free until the second norm
             TRY(llada_gather_rows_bf16(x, logit_rows, xc, R, d, M, stream));
             Ml = R;
@@ -120,8 +125,7 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
             al = h;
             hl = hc;
         }
-        TRY(llada_gemm_bf16(al, w->wo[l], xl, Ml, d, d, d, d, LLADA_EPI_RESIDUAL, xl, d, nullptr, nullptr, 0, sk, skb, stream));
-        TRY(llada_rmsnorm_bf16(xl, w->ff_norm[l], hl, Ml, d, c.rms_eps, nullptr, stream));
+        TRY(llada_gemm_residual_rmsnorm_bf16(al, w->wo[l], xl, hl, w->ff_norm[l], c.rms_eps, Ml, d, d, d, sk, skb, stream));
         if (w->packed) {
             TRY(llada_gemm_bf16(hl, w->wgu[l], act, Ml, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr,
                                 0, sk, skb, stream));
@@ -130,13 +134,24 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
                                 nullptr, 0, sk, skb, stream));
             TRY(llada_swiglu_bf16(gu, act, Ml, F, stream));
         }
-        TRY(llada_gemm_bf16(act, w->wdown[l], xl, Ml, d, F, F, d, LLADA_EPI_RESIDUAL, xl, d, nullptr, nullptr, 0,
-                            sk, skb, stream));
+        if (!last) {
+            TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], x, h, w->attn_norm[l + 1], c.rms_eps, M, d, F, F, sk,
+                                                 skb, stream));
+        } else if (prune) {   // the compacted rows are exactly the rows of the final norm
+            TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], xl, hf, w->ln_f, c.rms_eps, Ml, d, F, F, sk, skb,
+                                                 stream));
+            final_norm_done = true;
+        } else {
+            TRY(llada_gemm_bf16(act, w->wdown[l], xl, Ml, d, F, F, d, LLADA_EPI_RESIDUAL, xl, d, nullptr, nullptr, 0,
+                                sk, skb, stream));
+        }
     }
-    if (prune && c.n_layers > 0)
-        TRY(llada_rmsnorm_bf16(xc, w->ln_f, hf, R, d, c.rms_eps, nullptr, stream));
-    else
-        TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, R, d, c.rms_eps, logit_rows, stream));
+    if (!final_norm_done) {
+        if (prune && c.n_layers > 0)
+            TRY(llada_rmsnorm_bf16(xc, w->ln_f, hf, R, d, c.rms_eps, nullptr, stream));
+        else
+            TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, R, d, c.rms_eps, logit_rows, stream));
+    }
     TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, R, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
                         nullptr, 0, sk, skb, stream));
     return LLADA_OK;

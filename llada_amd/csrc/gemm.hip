@@ -40,6 +40,11 @@ struct GemmParams {
     int no_store;   // diagnostic: skip the epilogue stores (timing experiments only)
     int band_m;     // M tiles per band of the tile walk
     int remap;      // 1: XCD-aware block -> tile map
+    // RMSNorm of the updated residual stream fused into the split-K second pass (EPI_RESIDUAL only):
+    const bf16_t* norm_w;   // [N] norm weight, or nullptr
+    bf16_t* norm_out;       // [M, N] normalised rows
+    float norm_eps;
+    int* norm_fused;        // host flag: set to 1 when the second pass produced norm_out
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -812,6 +817,74 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
+// Second pass of a split-K GEMM with the residual epilogue, fused with the RMSNorm that follows it in
+// the model (attn_out -> ff_norm, ff_out -> next attn_norm / final norm): one workgroup per row adds
+// the float32 partial tiles in split order, adds the residual, stores the new residual row and its
+// normalised copy.  Same arithmetic and the same summation order as splitk_reduce_kernel<RESIDUAL>
+// followed by rmsnorm_kernel (elementwise.hip), so the results are bit-identical to the two kernels.
+template <int MAXV>
+__global__ void __launch_bounds__(256) splitk_reduce_norm_kernel(const GemmParams p) {
+    __shared__ float red[4];
+    const int chunks = p.N / 8;
+    const int tid = threadIdx.x;
+    const size_t slab_stride = (size_t)p.M * p.N;
+    for (int m = blockIdx.x; m < p.M; m += gridDim.x) {
+        u16x8 v[MAXV];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = tid + i * 256;
+            if (c < chunks) {
+                const float* src = p.slab + (size_t)m * p.N + c * 8;
+                f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+                for (int sidx = 1; sidx < p.splits; ++sidx) {
+                    const f32x4 ta = *(const f32x4*)(src + sidx * slab_stride);
+                    const f32x4 tb = *(const f32x4*)(src + sidx * slab_stride + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] += ta[e];
+                        b[e] += tb[e];
+                    }
+                }
+                const u16x8 r = *(const u16x8*)(p.R + (size_t)m * p.ldr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[i][e] = f32_to_bf16(bf16_to_f32(r[e]) + round_bf16(a[e]));
+                    v[i][4 + e] = f32_to_bf16(bf16_to_f32(r[4 + e]) + round_bf16(b[e]));
+                }
+                *(u16x8*)(p.C + (size_t)m * p.ldc + c * 8) = v[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf16_to_f32(v[i][e]);
+                    ss += f * f;
+                }
+            }
+        }
+        ss = wave_reduce_sum(ss);
+        __syncthreads();  // red[] reuse across rows
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float rs = rsqrtf(tot / (float)p.N + p.norm_eps);
+        const u16x8* wp = (const u16x8*)p.norm_w;
+        u16x8* op = (u16x8*)(p.norm_out + (size_t)m * p.N);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = tid + i * 256;
+            if (c < chunks) {
+                const u16x8 wv = wp[c];
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xn = round_bf16(bf16_to_f32(v[i][e]) * rs);
+                    o[e] = f32_to_bf16(xn * bf16_to_f32(wv[e]));
+                }
+                op[c] = o;
+            }
+        }
+    }
+}
+
 int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel, 2 the persistent stream kernel, 3 never it
 int g_stream_grid = 256;  // workgroups of the persistent kernel (one per CU)
 int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
@@ -913,6 +986,18 @@ int launch(const GemmParams& p, hipStream_t stream) {
     if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
     const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
     if (rc != LLADA_OK) return rc;
+    if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+        if (q.norm_out && q.norm_w && q.N % 8 == 0 && q.N <= 256 * 8 * 4) {
+            const int rgrid = q.M < 8192 ? q.M : 8192;
+            if (q.N <= 256 * 8 * 2)
+                hipLaunchKernelGGL((splitk_reduce_norm_kernel<2>), dim3(rgrid), dim3(256), 0, stream, q);
+            else
+                hipLaunchKernelGGL((splitk_reduce_norm_kernel<4>), dim3(rgrid), dim3(256), 0, stream, q);
+            LLADA_CHECK_LAUNCH("splitk_reduce_norm_kernel");
+            if (q.norm_fused) *q.norm_fused = 1;
+            return LLADA_OK;
+        }
+    }
     const int64_t items = (int64_t)p.M * p.N / 4;
     const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(grid), dim3(256), 0, stream, q);
@@ -1085,6 +1170,48 @@ static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, 
             llada_set_error("gemm: unknown epilogue %d", epilogue);
             return LLADA_ERR_INVALID;
     }
+}
+
+// X[M, N] += A[M, K] W[N, K]^T and H = RMSNorm(X) * norm_w: a residual projection followed by the norm
+// that consumes it.  When the GEMM runs split-K (small M) the second pass produces both outputs; otherwise
+// this is llada_gemm_bf16(EPI_RESIDUAL) followed by llada_rmsnorm_bf16.  Bit-identical either way.
+extern "C" int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, void* X, void* H, const void* norm_w,
+                                                float eps, int64_t M, int32_t N, int32_t K, int32_t lda,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+    LLADA_CHECK_ARG(A && W && X && H && norm_w, "gemm_residual_rmsnorm: null operand");
+    LLADA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_residual_rmsnorm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    LLADA_CHECK_SUPPORTED(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
+    LLADA_CHECK_SUPPORTED(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
+    LLADA_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)X & 15) == 0 &&
+                        ((uintptr_t)H & 15) == 0 && ((uintptr_t)norm_w & 15) == 0,
+                    "gemm_residual_rmsnorm: operands must be 16-byte aligned");
+    LLADA_CHECK_SUPPORTED(M < (1ll << 31), "gemm: M too large");
+    LLADA_CHECK_ARG(lda >= K && (lda % 8) == 0, "gemm: lda=%d must be >= K and a multiple of 8", lda);
+    GemmParams p{};
+    p.A = (const bf16_t*)A;
+    p.W = (const bf16_t*)W;
+    p.C = (bf16_t*)X;
+    p.R = (const bf16_t*)X;
+    p.M = (int)M;
+    p.N = N;
+    p.K = K;
+    p.lda = lda;
+    p.ldc = N;
+    p.ldr = N;
+    p.slab = (float*)workspace;
+    p.splits = 1;
+    int fused = 0;
+    p.norm_w = (const bf16_t*)norm_w;
+    p.norm_out = (bf16_t*)H;
+    p.norm_eps = eps;
+    p.norm_fused = &fused;
+    g_slab_bytes = workspace ? workspace_bytes : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
+    LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
+    const int rc = dispatch_mfr<LLADA_EPI_RESIDUAL>(p, mfr, s);
+    if (rc != LLADA_OK || fused) return rc;
+    return llada_rmsnorm_bf16(X, norm_w, H, M, N, eps, nullptr, stream);
 }
 
 // Bytes of float32 scratch with which llada_gemm_bf16 can balance this shape over all CUs (0 if it

@@ -220,6 +220,44 @@ def test_gemm_residual(lib):
     assert np.array_equal(host(Rt), ref)
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(96, 512, 1024, 4), (384, 4096, 4096, 0), (384, 4096, 12288, 0),
+                                          (200, 8192, 512, 2), (1024, 512, 256, 0), (3072, 4096, 4096, 0)])
+def test_gemm_residual_rmsnorm_fused(lib, M, N, K, splits):
+    """Projection + residual + the norm that follows: the fused entry point (norm folded into the
+    split-K second pass when there is one) equals the residual GEMM followed by the RMSNorm kernel
+    bit for bit, and matches the oracle's arithmetic."""
+    g = np.random.Generator(np.random.PCG64(M + N + K))
+    A = bf(g.standard_normal((M, K), dtype=np.float32))
+    W = bf(g.standard_normal((N, K), dtype=np.float32) * 0.05)
+    X0 = bf(g.standard_normal((M, N), dtype=np.float32) * 2)
+    nw = bf(1.0 + 0.1 * g.standard_normal(N, dtype=np.float32))
+    ws = torch.empty(int(lib.llada_gemm_workspace_bytes(M, N, K)) or 16, dtype=torch.uint8, device="cuda")
+    eps = 1e-5
+    lib.llada_gemm_force_splits(splits)
+    try:
+        # reference: two kernels
+        X1 = X0.clone()
+        check(lib, lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), X1.data_ptr(), M, N, K, K, N, 1, X1.data_ptr(), N,
+                                       None, None, 0, ws.data_ptr(), ws.numel(), stream()))
+        H1 = torch.empty_like(X1)
+        check(lib, lib.llada_rmsnorm_bf16(X1.data_ptr(), nw.data_ptr(), H1.data_ptr(), M, N, eps, None, stream()))
+        # fused
+        X2 = X0.clone()
+        H2 = torch.full_like(X2, float("nan"))
+        check(lib, lib.llada_gemm_residual_rmsnorm_bf16(A.data_ptr(), W.data_ptr(), X2.data_ptr(), H2.data_ptr(),
+                                                        nw.data_ptr(), eps, M, N, K, K, ws.data_ptr(), ws.numel(),
+                                                        stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.llada_gemm_force_splits(0)
+    assert torch.equal(X1, X2) and torch.equal(H1, H2)
+    x = host(X2)
+    # two roundings (x * rstd, then * w): a 1-ulp difference of the first can move the second by one more
+    ref_h = omodel.rmsnorm(x, host(nw), eps, True)
+    ud = ulp_distance(host(H2), ref_h)
+    assert ud.max() <= 2 and (ud <= 1).mean() >= 0.999
+
+
 def test_gemm_rope_epilogue(lib):
     """Packed QKV projection + rotary embedding == natural projection followed by the oracle's rope."""
     from llada_amd.weights import head_permutation, pack_qkv
