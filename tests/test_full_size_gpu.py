@@ -130,3 +130,50 @@ def test_likelihood_matches_oracle_on_hip_logits(model8b):
     a = get_log_likelihood(model8b, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=64, batch_size=32, seed=3)
     b = get_log_likelihood(model8b, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=64, batch_size=32, seed=3)
     assert a == b and a < 0
+
+
+def test_maximum_context_and_all_ones_mask(model8b):
+    """The longest context the reference allows (4096 tokens: 3072 prompt + 1024 generated in one
+    block, 128 tokens per step): exact transfer counts, and an all-ones attention_mask (the additive
+    key bias is 0 everywhere) gives the same tokens as no mask at all."""
+    from llada_amd import generate
+    P, G, steps = 3072, 1024, 8
+    prompt = prompts(1, P, seed=21)
+    trace = []
+    out = generate(model8b, prompt, steps=steps, gen_length=G, block_length=G, temperature=0., remasking="low_confidence",
+                   step_callback=lambda b, s, x, x0, c: trace.append(int((x == MASK_ID).sum().item())))
+    assert trace == [G - 128 * (i + 1) for i in range(steps)]
+    assert not (out == MASK_ID).any() and torch.equal(out[0, :P].cpu(), prompt[0])
+    masked = generate(model8b, prompt, torch.ones(1, P, dtype=torch.long), steps=steps, gen_length=G, block_length=G,
+                      temperature=0., remasking="low_confidence")
+    assert torch.equal(out, masked)
+
+
+def test_empty_prompt_and_wide_batch(model8b):
+    """No prompt at all (P = 0: every position starts masked) and a 64-row batch (the north-star batch on
+    one GPU) with a short schedule: shapes, transfer counts, no mask token left."""
+    from llada_amd import generate
+    out = generate(model8b, torch.zeros((2, 0), dtype=torch.long), steps=4, gen_length=32, block_length=16, temperature=0.)
+    assert tuple(out.shape) == (2, 32) and not (out == MASK_ID).any()
+    prompt = prompts(64, 16, seed=5)
+    counts = []
+    out = generate(model8b, prompt, steps=4, gen_length=32, block_length=16, temperature=0., remasking="random", seed=3,
+                   step_callback=lambda b, s, x, x0, c: counts.append((x == MASK_ID).sum(dim=1).cpu().numpy().copy()))
+    assert tuple(out.shape) == (64, 48) and not (out == MASK_ID).any()
+    assert np.array_equal(np.stack(counts), np.repeat(np.array([24, 16, 8, 0])[:, None], 64, axis=1))
+
+
+def test_likelihood_iteration_count_edge_cases(model8b):
+    """mc_num // batch_size iterations (the remainder is dropped, get_log_likelihood.py:66); none at all
+    divides by zero at :77, as in the reference."""
+    from llada_amd import get_log_likelihood
+    g = np.random.Generator(np.random.PCG64(9))
+    prompt = torch.from_numpy(g.integers(0, 126000, size=24, dtype=np.int64))
+    answer = torch.from_numpy(g.integers(0, 126000, size=8, dtype=np.int64))
+    a = get_log_likelihood(model8b, prompt, answer, mc_num=8, batch_size=4, seed=1)
+    b = get_log_likelihood(model8b, prompt, answer, mc_num=11, batch_size=4, seed=1)     # 11 // 4 == 2 iterations too
+    assert a == b
+    with pytest.raises(ZeroDivisionError):
+        get_log_likelihood(model8b, prompt, answer, mc_num=3, batch_size=4)
+    one = get_log_likelihood(model8b, prompt, answer[:1], mc_num=4, batch_size=4, seed=2)   # single-token answer
+    assert np.isfinite(one) and one < 0
