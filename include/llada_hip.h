@@ -164,6 +164,34 @@ int llada_swiglu_bf16(const void* gu, void* out, int64_t n_rows, int32_t F, void
 int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, void* out, int32_t n_seq, int32_t seq_len,
                           int32_t n_heads, void* stream);
 
+/* The same attention for a subset of the positions: q [n_seq*n_q, q_stride] (n_q query rows per sequence,
+ * head h at columns h*128) over all seq_len keys/values of a [Q | K | V] image kv [n_seq*seq_len, 3*d];
+ * out [n_seq*n_q, d].  Used by the block-cached sampler (llada_forward_block). */
+int llada_attn_bidir_queries_bf16(const void* q, int64_t q_stride, int32_t n_q, const void* kv, const uint8_t* key_mask,
+                                  void* out, int32_t n_seq, int32_t seq_len, int32_t n_heads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Block-cached forward.  No counterpart in the reference, whose sampler recomputes every position at
+ * every step (generate.py:80-92; README.md:110-116 names the missing cache as the reason it is slow
+ * and points to Fast-dLLM / dLLM-Cache, README.md:127-130).  An opt-in APPROXIMATION of the sampler:
+ * llada_forward_fill_cache is llada_forward that also leaves every layer's [Q | K | V] image
+ * ([n_layers][n_seq*seq_len][3*d] bf16, llada_kv_cache_bytes) in kv_cache; llada_forward_block then
+ * recomputes only the block_len positions from block_start of every sequence (block_ids
+ * [n_seq, block_len]): their keys/values replace the cached ones, their queries attend over the whole
+ * cached sequence, and logits_out [n_seq*block_len, vocab] holds their logits.  Keys and values of the
+ * other positions stay as they were when the cache was filled.
+ * ------------------------------------------------------------------------------------------- */
+size_t llada_kv_cache_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len);
+int llada_forward_fill_cache(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
+                             const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
+                             int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out,
+                             void* workspace, size_t workspace_bytes, void* kv_cache, void* stream);
+size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t block_len);
+int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
+                        const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
+                        int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache, void* logits_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sampler epilogue: replaces generate.py:81-134 after the forward.
  * ------------------------------------------------------------------------------------------- */

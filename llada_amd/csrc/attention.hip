@@ -37,8 +37,9 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1))
-attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out,
-                      int L, int d, float scale_log2e) {
+attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, const bf16_t* __restrict__ kv_src,
+                      int64_t kv_stride, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out, int L, int d,
+                      float scale_log2e) {
     constexpr int TILE_BYTES = KT * 256;           // one operand, one tile
     constexpr int BUF_BYTES = 2 * TILE_BYTES;      // K then V
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES + 2 * KT * 4];
@@ -49,8 +50,10 @@ attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ ke
     const int r = lane & 31, hg = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * (NW * 32) + wave * 32;
-    const size_t row_stride = (size_t)3 * d;
-    const bf16_t* base = qkv + (size_t)b * L * row_stride + (size_t)h * HD;
+    // queries: n_q rows per sequence (row stride q_stride, head h at column h * HD); keys and values: L rows per
+    // sequence of a [.. | K | V] image (row stride kv_stride, K at column d, V at column 2 d)
+    const size_t row_stride = (size_t)kv_stride;
+    const bf16_t* base = kv_src + (size_t)b * L * row_stride + (size_t)h * HD;
 
     // ---- DMA: a tile is 32 pieces of 1 KiB (4 keys x 256 B): pieces 0-15 = K, 16-31 = V ----
     const int p_row = lane >> 4, p_slot = lane & 15;
@@ -87,8 +90,8 @@ attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ ke
     // Q fragments: B operand of S^T = K Q^T, lane holds Q[q0 + r][16*ds + 8*hg .. +7]
     bf16x8 qf[8];
     {
-        const int q = min(q0 + r, L - 1);
-        const bf16_t* qp = base + (size_t)q * row_stride + hg * 8;
+        const int q = min(q0 + r, n_q - 1);
+        const bf16_t* qp = q_src + ((size_t)b * n_q + q) * (size_t)q_stride + (size_t)h * HD + hg * 8;
 #pragma unroll
         for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 16);
     }
@@ -195,8 +198,8 @@ attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ ke
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + r;
-    if (q < L) {
-        bf16_t* op = out + ((size_t)b * L + q) * d + (size_t)h * HD + 4 * hg;
+    if (q < n_q) {
+        bf16_t* op = out + ((size_t)b * n_q + q) * d + (size_t)h * HD + 4 * hg;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -211,10 +214,11 @@ attn_bidir_kernel(const bf16_t* __restrict__ qkv, const uint8_t* __restrict__ ke
 }
 
 template <int NW>
-void launch_attn(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* out, int n_seq, int L, int H, int d, float scale,
-                 hipStream_t stream) {
-    dim3 grid((L + NW * 32 - 1) / (NW * 32), H, n_seq);
-    hipLaunchKernelGGL((attn_bidir_kernel<NW>), grid, dim3(NW * 64), 0, stream, qkv, key_mask, out, L, d, scale);
+void launch_attn(const bf16_t* q, int64_t q_stride, int n_q, const bf16_t* kv, int64_t kv_stride, const uint8_t* key_mask,
+                 bf16_t* out, int n_seq, int L, int H, int d, float scale, hipStream_t stream) {
+    dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq);
+    hipLaunchKernelGGL((attn_bidir_kernel<NW>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride, key_mask,
+                       out, L, d, scale);
 }
 
 int g_attn_variant = 0;   // test hook: waves per workgroup (1, 2, 4), 0 = automatic
@@ -223,26 +227,45 @@ int g_attn_variant = 0;   // test hook: waves per workgroup (1, 2, 4), 0 = autom
 
 extern "C" void llada_attn_force_variant(int v) { g_attn_variant = v; }
 
+static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16_t* kvp, int64_t kv_stride,
+                         const uint8_t* key_mask, bf16_t* op, int n_seq, int seq_len, int n_heads, hipStream_t st) {
+    const int d = n_heads * HD;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+    // Waves per workgroup: 4 (128 queries), fewer when a sequence has fewer queries than that.  More waves per
+    // workgroup (up to one workgroup per (sequence, head), K/V fetched once) were measured slower at
+    // every benchmark shape: the per-tile barrier phase-locks the waves that share a SIMD.
+    const int q_waves = (n_q + 31) / 32;
+    const int nw = g_attn_variant > 0 ? g_attn_variant : (q_waves >= 4 ? 4 : (q_waves >= 2 ? 2 : 1));
+    switch (nw) {
+        case 4: launch_attn<4>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
+        case 2: launch_attn<2>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
+        default: launch_attn<1>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
+    }
+    LLADA_CHECK_LAUNCH("attn_bidir_kernel");
+    return LLADA_OK;
+}
+
 extern "C" int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, void* out, int32_t n_seq,
                                      int32_t seq_len, int32_t n_heads, void* stream) {
     LLADA_CHECK_ARG(qkv && out, "attn: null operand");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_heads > 0, "attn: bad shape");
     LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
-    const int d = n_heads * HD;
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
-    // Waves per workgroup: 4 (128 queries), fewer for sequences shorter than that.  More waves per
-    // workgroup (up to one workgroup per (sequence, head), K/V fetched once) were measured slower at
-    // every benchmark shape: the per-tile barrier phase-locks the waves that share a SIMD.
-    const int q_waves = (seq_len + 31) / 32;
-    const int nw = g_attn_variant > 0 ? g_attn_variant : (q_waves >= 4 ? 4 : (q_waves >= 2 ? 2 : 1));
-    const bf16_t* qp = (const bf16_t*)qkv;
-    bf16_t* op = (bf16_t*)out;
-    hipStream_t st = (hipStream_t)stream;
-    switch (nw) {
-        case 4: launch_attn<4>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        case 2: launch_attn<2>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        default: launch_attn<1>(qp, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-    }
-    LLADA_CHECK_LAUNCH("attn_bidir_kernel");
-    return LLADA_OK;
+    const int64_t stride = (int64_t)3 * n_heads * HD;
+    return attn_dispatch((const bf16_t*)qkv, stride, seq_len, (const bf16_t*)qkv, stride, key_mask, (bf16_t*)out, n_seq,
+                         seq_len, n_heads, (hipStream_t)stream);
+}
+
+// Attention of a subset of the positions: n_q query rows per sequence (q [n_seq * n_q, q_stride], head h at column
+// h * 128) over all seq_len keys and values of a [Q | K | V] image kv [n_seq * seq_len, 3 d] (the per-layer cache of
+// the block-cached sampler).  out [n_seq * n_q, d].
+extern "C" int llada_attn_bidir_queries_bf16(const void* q, int64_t q_stride, int32_t n_q, const void* kv,
+                                             const uint8_t* key_mask, void* out, int32_t n_seq, int32_t seq_len,
+                                             int32_t n_heads, void* stream) {
+    LLADA_CHECK_ARG(q && kv && out, "attn_queries: null operand");
+    LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_heads > 0 && n_q > 0, "attn_queries: bad shape");
+    LLADA_CHECK_ARG(q_stride >= (int64_t)n_heads * HD && (q_stride % 8) == 0 && ((uintptr_t)q & 15) == 0,
+                    "attn_queries: q_stride must cover the heads and keep rows 16-byte aligned");
+    LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
+    return attn_dispatch((const bf16_t*)q, q_stride, n_q, (const bf16_t*)kv, (int64_t)3 * n_heads * HD, key_mask,
+                         (bf16_t*)out, n_seq, seq_len, n_heads, (hipStream_t)stream);
 }

@@ -59,10 +59,59 @@ extern "C" size_t llada_forward_workspace_bytes(const llada_config* cfg, int32_t
         if (rc_ != LLADA_OK) return rc_; \
     } while (0)
 
+namespace {
+
+// Copies the K | V thirds of the compact rows of one block (qkv_b [n_seq * block_len, 3 d]) into the rows
+// seq * seq_len + block_start + i of a per-layer [Q | K | V] image.
+__global__ void __launch_bounds__(256) scatter_kv_kernel(const bf16_t* __restrict__ qkv_b, bf16_t* __restrict__ image,
+                                                         int64_t n_rows, int block_len, int seq_len, int block_start,
+                                                         int d) {
+    const int chunks = 2 * d / 8;   // 16-byte pieces of K | V per row
+    const int64_t total = n_rows * chunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        const int64_t dst_row = (r / block_len) * seq_len + block_start + (r % block_len);
+        *(u32x4*)(image + dst_row * 3 * d + d + c * 8) = *(const u32x4*)(qkv_b + r * 3 * d + d + c * 8);
+    }
+}
+
+int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t* ids, const uint8_t* key_mask,
+                 const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
+                 const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,
+                 size_t workspace_bytes, void* kv_cache, void* stream);
+
+}  // namespace
+
 extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
                              const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                              int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out,
                              void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_impl(cfg, w, ids, key_mask, rope_cos, rope_sin, n_seq, seq_len, logit_rows, n_logit_rows, logits_out,
+                        workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" size_t llada_kv_cache_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len) {
+    if (!cfg || n_seq <= 0 || seq_len <= 0) return 0;
+    return (size_t)cfg->n_layers * n_seq * seq_len * 3 * cfg->d_model * 2;
+}
+
+extern "C" int llada_forward_fill_cache(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
+                                        const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                                        int32_t n_seq, int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows,
+                                        void* logits_out, void* workspace, size_t workspace_bytes, void* kv_cache,
+                                        void* stream) {
+    LLADA_CHECK_ARG(kv_cache != nullptr && ((uintptr_t)kv_cache & 255) == 0, "forward_fill_cache: kv_cache must be 256-byte aligned");
+    return forward_impl(cfg, w, ids, key_mask, rope_cos, rope_sin, n_seq, seq_len, logit_rows, n_logit_rows, logits_out,
+                        workspace, workspace_bytes, kv_cache, stream);
+}
+
+namespace {
+
+int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t* ids, const uint8_t* key_mask,
+                 const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
+                 const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,
+                 size_t workspace_bytes, void* kv_cache, void* stream) {
     LLADA_CHECK_ARG(cfg && w && ids && rope_cos && rope_sin && logits_out && workspace, "forward: null argument");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_logit_rows > 0, "forward: bad shape");
     const llada_config& c = *cfg;
@@ -79,7 +128,8 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     unsigned char* ws = (unsigned char*)workspace;
     void* x = ws + lay.x;
     void* h = ws + lay.h;
-    void* qkv = ws + lay.qkv;
+    void* const qkv_ws = ws + lay.qkv;
+    void* qkv = qkv_ws;
     void* att = ws + lay.att;
     void* act = ws + lay.act;
     void* gu = ws + lay.gu;
@@ -93,8 +143,8 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     // final norm run on those rows alone.  Scratch: the qkv buffer is dead after attention.
     const bool prune = logit_rows != nullptr && (int64_t)n_logit_rows * 2 <= M;
     const int64_t R = n_logit_rows;
-    void* xc = qkv;                                     // [R, d] compacted residual stream
-    void* hc = (unsigned char*)qkv + (size_t)R * d * 2; // [R, d] its norm
+    void* xc = qkv_ws;                                     // [R, d] compacted residual stream
+    void* hc = (unsigned char*)qkv_ws + (size_t)R * d * 2; // [R, d] its norm
 
     TRY(llada_embed_bf16(w->wte, ids, x, M, d, V, stream));
     // Every residual projection is issued together with the norm that reads its result (the output
@@ -104,6 +154,8 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     bool final_norm_done = false;
     for (int l = 0; l < c.n_layers; ++l) {
         const bool last = l == c.n_layers - 1;
+        // with a cache every layer leaves its [Q | K | V] image there instead of in the shared scratch
+        if (kv_cache) qkv = (unsigned char*)kv_cache + (size_t)l * M * 3 * d * 2;
         if (w->packed) {
             TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, rope_cos,
                                 rope_sin, seq_len, sk, skb, stream));
@@ -155,4 +207,90 @@ extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, co
     TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, R, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
                         nullptr, 0, sk, skb, stream));
     return LLADA_OK;
+}
+
+}  // namespace
+
+// One denoising step of the block-cached sampler: only the block_len positions starting at block_start of
+// every sequence are recomputed (block_ids [n_seq, block_len]); their keys and values replace the cached ones
+// and their queries attend over the whole cached sequence.  logits_out [n_seq * block_len, vocab].
+extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
+                                   const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
+                                   int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache,
+                                   void* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
+    LLADA_CHECK_ARG(cfg && w && block_ids && rope_cos && rope_sin && logits_out && workspace && kv_cache,
+                    "forward_block: null argument");
+    LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && block_len > 0 && block_start >= 0 && block_start + block_len <= seq_len,
+                    "forward_block: bad shape");
+    const llada_config& c = *cfg;
+    LLADA_CHECK_SUPPORTED(c.n_heads > 0 && c.d_model == c.n_heads * 128, "forward: head_dim must be 128");
+    LLADA_CHECK_SUPPORTED(c.d_model % 256 == 0 && c.mlp_hidden % 64 == 0 && c.vocab_size % 8 == 0,
+                          "forward: d_model %% 256, mlp_hidden %% 64, vocab %% 8 must be 0");
+    const int64_t Mb = (int64_t)n_seq * block_len;
+    const int64_t M = (int64_t)n_seq * seq_len;
+    const Layout lay = make_layout(c, Mb, Mb);
+    if (workspace_bytes < lay.total) {
+        llada_set_error("forward_block: workspace has %zu bytes, %zu needed", workspace_bytes, lay.total);
+        return LLADA_ERR_WORKSPACE;
+    }
+    unsigned char* ws = (unsigned char*)workspace;
+    void* x = ws + lay.x;
+    void* h = ws + lay.h;
+    void* qkv = ws + lay.qkv;
+    void* att = ws + lay.att;
+    void* act = ws + lay.act;
+    void* gu = ws + lay.gu;
+    void* hf = ws + lay.hf;
+    void* sk = lay.splitk_bytes ? ws + lay.splitk : nullptr;
+    const size_t skb = lay.splitk_bytes;
+    const int d = c.d_model, F = c.mlp_hidden, V = c.vocab_size;
+    // rotary tables of the block's positions: row block_start onwards, period block_len
+    const float* cos_b = rope_cos + (size_t)block_start * 64;
+    const float* sin_b = rope_sin + (size_t)block_start * 64;
+    hipStream_t st = (hipStream_t)stream;
+
+    TRY(llada_embed_bf16(w->wte, block_ids, x, Mb, d, V, stream));
+    if (c.n_layers > 0) TRY(llada_rmsnorm_bf16(x, w->attn_norm[0], h, Mb, d, c.rms_eps, nullptr, stream));
+    for (int l = 0; l < c.n_layers; ++l) {
+        const bool last = l == c.n_layers - 1;
+        bf16_t* image = (bf16_t*)((unsigned char*)kv_cache + (size_t)l * M * 3 * d * 2);
+        if (w->packed) {
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, Mb, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, cos_b, sin_b,
+                                block_len, sk, skb, stream));
+        } else {
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, Mb, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN, nullptr, 0, nullptr, nullptr,
+                                0, sk, skb, stream));
+            TRY(llada_rope_bf16(qkv, cos_b, sin_b, n_seq, block_len, c.n_heads, stream));
+        }
+        {
+            const int64_t total = Mb * (2 * d / 8);
+            const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+            hipLaunchKernelGGL(scatter_kv_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)qkv, image, Mb, block_len,
+                               seq_len, block_start, d);
+            LLADA_CHECK_LAUNCH("scatter_kv_kernel");
+        }
+        TRY(llada_attn_bidir_queries_bf16(qkv, (int64_t)3 * d, block_len, image, key_mask, att, n_seq, seq_len, c.n_heads,
+                                          stream));
+        TRY(llada_gemm_residual_rmsnorm_bf16(att, w->wo[l], x, h, w->ff_norm[l], c.rms_eps, Mb, d, d, d, sk, skb, stream));
+        if (w->packed) {
+            TRY(llada_gemm_bf16(h, w->wgu[l], act, Mb, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr, 0,
+                                sk, skb, stream));
+        } else {
+            TRY(llada_gemm_bf16(h, w->wgu[l], gu, Mb, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr, nullptr,
+                                0, sk, skb, stream));
+            TRY(llada_swiglu_bf16(gu, act, Mb, F, stream));
+        }
+        TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], x, last ? hf : h, last ? w->ln_f : w->attn_norm[l + 1],
+                                             c.rms_eps, Mb, d, F, F, sk, skb, stream));
+    }
+    if (c.n_layers == 0) TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, Mb, d, c.rms_eps, nullptr, stream));
+    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, Mb, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr, nullptr, 0, sk,
+                        skb, stream));
+    return LLADA_OK;
+}
+
+extern "C" size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t block_len) {
+    if (!cfg || n_seq <= 0 || block_len <= 0) return 0;
+    const int64_t Mb = (int64_t)n_seq * block_len;
+    return make_layout(*cfg, Mb, Mb).total;
 }

@@ -43,7 +43,7 @@ def get_num_transfer_tokens(mask_index, steps):
 def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, block_length=128, temperature=0.,
              cfg_scale=0., remasking='low_confidence', mask_id=126336, logits_eos_inf=False,
              confidence_eos_eot_inf=False, *, seed=0, row_offset=0, noise_fn=None, rand_fn=None,
-             step_callback=None):
+             step_callback=None, cache=None):
     '''
     Args (generate.py:46-59):
         model: Mask predictor (llada_amd.LLaDAModel, or any object with .device and
@@ -58,6 +58,11 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         rand_fn(shape) -> float32 tensor [B, L]: replaces torch.rand (generate.py:121).
         step_callback(block, step, x, x0, confidence): called after every step (tensors are live
             device buffers; clone to keep).
+        cache: None (default) recomputes every position at every step, as the reference does.
+            "dual" is an APPROXIMATION outside the reference (llada_amd.LLaDAModel only): the first step
+            of each block runs the whole sequence and keeps every layer's keys and values; the block's
+            other steps recompute only the block's positions against those cached keys and values of the
+            rest of the sequence (prefix and suffix), which are then one block stale.
     '''
     lib = _lib.load()
     device = torch.device(model.device)
@@ -78,6 +83,11 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         raise NotImplementedError(remasking)                                              # :122-123
 
     fast = isinstance(model, LLaDAModel)
+    if cache not in (None, "dual"):
+        raise NotImplementedError(f"cache={cache!r}")
+    if cache is not None and not fast:
+        raise NotImplementedError("cache='dual' needs an llada_amd.LLaDAModel")
+    kv = model.kv_cache(2 * B if cfg_scale > 0.0 else B, L) if cache == "dual" else None
     V = model.cfg.vocab_size if fast else None
     x0 = torch.empty_like(x)
     conf = torch.empty((B, L), dtype=torch.float32, device=device)
@@ -107,7 +117,10 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                 un_x = torch.where(prompt_index, mask_id, x)
                 x_ = torch.cat([x, un_x], dim=0)
                 if fast:
-                    lg = model.forward_rows(x_, am2, rows2, out=logits_buf)
+                    if kv is not None and i > 0:
+                        lg = model.forward_block(x_[:, bs:be], am2, L, bs, kv, out=logits_buf)
+                    else:
+                        lg = model.forward_rows(x_, am2, rows2, out=logits_buf, kv_cache=kv)
                     cond, un = lg[:n_rows], lg[n_rows:]
                     row_pos, nr = rows, n_rows
                 else:
@@ -117,8 +130,11 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                     row_pos, nr = None, B * L
                 un_ptr = un.data_ptr()
             else:
-                if fast:
-                    cond = model.forward_rows(x, attention_mask, rows, out=logits_buf)   # :92
+                if fast and kv is not None and i > 0:
+                    cond = model.forward_block(x[:, bs:be], attention_mask, L, bs, kv, out=logits_buf)
+                    row_pos, nr = rows, n_rows
+                elif fast:
+                    cond = model.forward_rows(x, attention_mask, rows, out=logits_buf, kv_cache=kv)   # :92
                     row_pos, nr = rows, n_rows
                 else:
                     lg = model(x, attention_mask=attention_mask).logits

@@ -35,6 +35,7 @@ class LLaDAModel:
         self._c_w = _lib.Weights(1 if w.packed else 0, w.wte.data_ptr(), w.ln_f.data_ptr(), w.lm_head.data_ptr(),
                                  *[C.cast(a, C.POINTER(C.c_void_p)) for a in self._arrays])
         self._ws = None
+        self._ws_block = None
         self._rope = {}
 
     # -- HF-like surface the reference's callers touch -------------------------------------------
@@ -64,9 +65,42 @@ class LLaDAModel:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward_rows(self, input_ids, attention_mask=None, logit_rows=None, out=None):
+    def kv_cache(self, n_seq, L):
+        """Storage for the block-cached sampler: every layer's [Q | K | V] image of n_seq x L tokens."""
+        need = self.lib.llada_kv_cache_bytes(C.byref(self._c_cfg), n_seq, L)
+        return torch.empty(need, dtype=torch.uint8, device=self.device)
+
+    def forward_block(self, block_ids, attention_mask, seq_len, block_start, kv_cache, out=None):
+        """Recompute only the positions [block_start, block_start + block_len) of every sequence
+        (block_ids [n_seq, block_len]) against ``kv_cache`` (filled by forward_rows(..., kv_cache=)): their
+        keys and values replace the cached ones.  ``attention_mask`` is the full [n_seq, seq_len] mask.
+        Returns bf16 logits [n_seq * block_len, V]."""
+        assert block_ids.dim() == 2 and block_ids.dtype == torch.long
+        ids = block_ids.to(self.device).contiguous()
+        n_seq, bl = ids.shape
+        km = None
+        if attention_mask is not None:
+            km = (attention_mask.to(self.device) != 0).to(torch.uint8).contiguous()
+            assert tuple(km.shape) == (n_seq, seq_len)
+        assert kv_cache.numel() >= self.lib.llada_kv_cache_bytes(C.byref(self._c_cfg), n_seq, seq_len)
+        cos, sin = self.rope_tables(seq_len)
+        if out is None:
+            out = torch.empty(n_seq * bl, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
+        need = self.lib.llada_forward_block_workspace_bytes(C.byref(self._c_cfg), n_seq, bl)
+        if self._ws_block is None or self._ws_block.numel() < need:
+            self._ws_block = None
+            self._ws_block = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws_block
+        _lib.check(self.lib.llada_forward_block(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
+                                                cos.data_ptr(), sin.data_ptr(), n_seq, seq_len, block_start, bl,
+                                                kv_cache.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                _lib.stream_ptr()))
+        return out
+
+    def forward_rows(self, input_ids, attention_mask=None, logit_rows=None, out=None, kv_cache=None):
         """Forward on ids [n_seq, L]; returns bf16 logits [n_rows, V] for the flat token indices in
-        ``logit_rows`` (int32 tensor) or for every token when it is None."""
+        ``logit_rows`` (int32 tensor) or for every token when it is None.  With ``kv_cache`` every layer's
+        [Q | K | V] image is left there for forward_block."""
         assert input_ids.dim() == 2 and input_ids.dtype == torch.long
         ids = input_ids.to(self.device).contiguous()
         n_seq, L = ids.shape
@@ -81,9 +115,16 @@ class LLaDAModel:
         if out is None:
             out = torch.empty(n_rows, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
         ws = self._workspace(n_seq, L, n_rows)
-        rc = self.lib.llada_forward(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
-                                    cos.data_ptr(), sin.data_ptr(), n_seq, L, _lib.ptr(logit_rows), n_rows,
-                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        if kv_cache is None:
+            rc = self.lib.llada_forward(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
+                                        cos.data_ptr(), sin.data_ptr(), n_seq, L, _lib.ptr(logit_rows), n_rows,
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        else:
+            assert kv_cache.numel() >= self.lib.llada_kv_cache_bytes(C.byref(self._c_cfg), n_seq, L)
+            rc = self.lib.llada_forward_fill_cache(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
+                                                   cos.data_ptr(), sin.data_ptr(), n_seq, L, _lib.ptr(logit_rows), n_rows,
+                                                   out.data_ptr(), ws.data_ptr(), ws.numel(), kv_cache.data_ptr(),
+                                                   _lib.stream_ptr())
         _lib.check(rc)
         return out
 

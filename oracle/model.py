@@ -101,8 +101,9 @@ def attention(q, k, v, key_mask, emulate):
     return _r(o, emulate)
 
 
-def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, return_hidden=False):
-    """ids int64 [B, L] -> logits float32 [B, L, V] (bf16 values when emulate_bf16)."""
+def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, return_hidden=False, kv_out=None):
+    """ids int64 [B, L] -> logits float32 [B, L, V] (bf16 values when emulate_bf16).  ``kv_out`` (a list)
+    receives every layer's rotated keys and values (k, v), each [B, H, L, D], for forward_block."""
     em = emulate_bf16
     ids = np.asarray(ids)
     B, L = ids.shape
@@ -118,6 +119,8 @@ def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, 
         v = _r(h @ W[p + "v_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
         q = apply_rope(q, cos, sin, em)
         k = apply_rope(k, cos, sin, em)
+        if kv_out is not None:
+            kv_out.append((k.copy(), v.copy()))
         a = attention(q, k, v, attention_mask, em).transpose(0, 2, 1, 3).reshape(B, L, H * D)
         x = _r(x + _r(a @ W[p + "attn_out"].T, em), em)
         h = rmsnorm(x, W[p + "ff_norm"], cfg.rms_eps, em)
@@ -128,6 +131,42 @@ def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, 
     hf = rmsnorm(x, W["ln_f"], cfg.rms_eps, em)
     if return_hidden:
         return hf
+    return _r(hf @ W["ff_out"].T, em)
+
+
+def forward_block(W, cfg, block_ids, block_start, kv, attention_mask=None, emulate_bf16=True):
+    """The block-cached step (no counterpart in the reference, whose sampler recomputes every position,
+    generate.py:80-92): only the positions block_start .. block_start + bl - 1 run through the layers.
+    Their keys and values replace the cached ones in ``kv`` (the list forward(kv_out=) filled, updated in
+    place); their queries attend over the whole cached sequence.  block_ids int64 [B, bl] -> logits
+    float32 [B, bl, V]; attention_mask is the full [B, L] key mask."""
+    em = emulate_bf16
+    block_ids = np.asarray(block_ids)
+    B, bl = block_ids.shape
+    H, D = cfg.n_heads, cfg.head_dim
+    L = kv[0][0].shape[2]
+    cos, sin = rope_tables(L, D, cfg.rope_theta)
+    cos, sin = cos[block_start:block_start + bl], sin[block_start:block_start + bl]
+    x = W["wte"][block_ids].astype(np.float32)
+    for i in range(cfg.n_layers):
+        p = f"blocks.{i}."
+        h = rmsnorm(x, W[p + "attn_norm"], cfg.rms_eps, em)
+        q = _r(h @ W[p + "q_proj"].T, em).reshape(B, bl, H, D).transpose(0, 2, 1, 3)
+        k = _r(h @ W[p + "k_proj"].T, em).reshape(B, bl, H, D).transpose(0, 2, 1, 3)
+        v = _r(h @ W[p + "v_proj"].T, em).reshape(B, bl, H, D).transpose(0, 2, 1, 3)
+        q = apply_rope(q, cos, sin, em)
+        k = apply_rope(k, cos, sin, em)
+        kc, vc = kv[i]
+        kc[:, :, block_start:block_start + bl] = k
+        vc[:, :, block_start:block_start + bl] = v
+        a = attention(q, kc, vc, attention_mask, em).transpose(0, 2, 1, 3).reshape(B, bl, H * D)
+        x = _r(x + _r(a @ W[p + "attn_out"].T, em), em)
+        h = rmsnorm(x, W[p + "ff_norm"], cfg.rms_eps, em)
+        g = _r(h @ W[p + "ff_proj"].T, em)
+        u = _r(h @ W[p + "up_proj"].T, em)
+        act = _r(g / (np.float32(1.0) + np.exp(-g)), em)     # silu
+        x = _r(x + _r(_r(act * u, em) @ W[p + "ff_out"].T, em), em)
+    hf = rmsnorm(x, W["ln_f"], cfg.rms_eps, em)
     return _r(hf @ W["ff_out"].T, em)
 
 
