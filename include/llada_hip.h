@@ -54,6 +54,12 @@ extern "C" {
 #define LLADA_EPI_RESIDUAL 1   /* C = bf16(R + bf16(acc)) */
 #define LLADA_EPI_ROPE_QKV 2   /* QKV projection with rotary embedding applied to Q and K (packed weight layout) */
 #define LLADA_EPI_SWIGLU 3     /* gate/up projection, C[m][f] = bf16(bf16(silu(gate)) * up) (packed weight layout) */
+/* ORed into the epilogue argument: W is stored tile-major -- every 256-row x 64-column block of the [N, K]
+ * matrix contiguous (256 rows of 128 bytes), the K/64 blocks of one 256-row band consecutive, bands in row
+ * order: element (n, k) at ((n/256 * K/64 + k/64) * 256 + n%256) * 64 + k%64.  One K step of one output tile
+ * then reads one contiguous 32 KiB run instead of 256 segments of 128 bytes at a stride of 2K bytes.
+ * Needs N % 256 == 0. */
+#define LLADA_GEMM_W_TILED 0x100
 
 int llada_abi_version(void);
 const char* llada_last_error(void);
@@ -83,8 +89,10 @@ typedef struct llada_config {
  *                       gate 16-31, up 16-31, ...
  *   wo[l] [d, d], wdown[l] [d, F], lm_head [V, d], wte [V, d]: as in the checkpoint.
  * The per-layer arrays are HOST arrays of n_layers device pointers.
- * packed == 0 selects the checkpoint layout instead (wqkv = q|k|v rows and wgu = gate|up rows in
- * natural order); the forward then runs the rotary embedding and SwiGLU as separate kernels. */
+ * packed is a bit set.  Bit 0 clear selects the checkpoint layout instead (wqkv = q|k|v rows and wgu =
+ * gate|up rows in natural order); the forward then runs the rotary embedding and SwiGLU as separate kernels.
+ * Bit 1 (value 2): wqkv, wo, wgu, wdown and lm_head are stored tile-major (LLADA_GEMM_W_TILED; the row order
+ * above is applied first); wte stays row-major. */
 typedef struct llada_weights {
     int32_t packed;
     const void* wte;
@@ -145,9 +153,10 @@ size_t llada_gemm_workspace_bytes(int64_t M, int32_t N, int32_t K);
  * H[M, N] = RMSNorm(X) * norm_w: a residual projection of the mask predictor (attn_out or ff_out, called at
  * generate.py:88,92 / get_log_likelihood.py:38) together with the norm that reads its result.  Bit-identical
  * to llada_gemm_bf16(EPI_RESIDUAL) followed by llada_rmsnorm_bf16; when the GEMM runs split-K (small M) the
- * second pass writes both outputs, which saves a kernel and a round trip of the residual stream. */
+ * second pass writes both outputs, which saves a kernel and a round trip of the residual stream.
+ * w_tiled != 0: W is tile-major (LLADA_GEMM_W_TILED). */
 int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, void* X, void* H, const void* norm_w, float eps,
-                                     int64_t M, int32_t N, int32_t K, int32_t lda, void* workspace,
+                                     int64_t M, int32_t N, int32_t K, int32_t lda, int32_t w_tiled, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
 /* In-place rotary embedding of the Q and K thirds of qkv [n_seq*seq_len, 3*d] (natural head

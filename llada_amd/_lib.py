@@ -17,6 +17,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
 REMASK = {"low_confidence": 0, "high_confidence": 1, "low_entropy": 2, "high_entropy": 3, "random": 4}
 FLAG_LOGITS_EOS_INF, FLAG_CONF_EOS_EOT_INF, FLAG_CONF_FLOAT32 = 1, 2, 4
 EPI_PLAIN, EPI_RESIDUAL, EPI_ROPE_QKV, EPI_SWIGLU = 0, 1, 2, 3
+GEMM_W_TILED = 0x100
 
 vp = C.c_void_p
 
@@ -52,7 +53,7 @@ SIGNATURES = {
     "llada_gather_rows_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp, vp]),
     "llada_gemm_residual_rmsnorm_bf16": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, C.c_int32,
-                                                   C.c_int32, vp, C.c_size_t, vp]),
+                                                   C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
     "llada_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
                                   C.c_int32, vp, vp, C.c_int32, vp, C.c_size_t, vp]),
     "llada_gemm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

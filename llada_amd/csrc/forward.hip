@@ -137,6 +137,8 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
     void* sk = lay.splitk_bytes ? ws + lay.splitk : nullptr;
     const size_t skb = lay.splitk_bytes;
     const int d = c.d_model, F = c.mlp_hidden, V = c.vocab_size;
+    const int tl = (w->packed & 2) ? 1 : 0;            // projection matrices stored tile-major
+    const int tf = tl ? LLADA_GEMM_W_TILED : 0;
 
     // In the last layer only the wanted rows matter once attention has mixed the tokens: they are
     // compacted (attention output and residual stream) and the output projection, the MLP and the
@@ -156,11 +158,11 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
         const bool last = l == c.n_layers - 1;
         // with a cache every layer leaves its [Q | K | V] image there instead of in the shared scratch
         if (kv_cache) qkv = (unsigned char*)kv_cache + (size_t)l * M * 3 * d * 2;
-        if (w->packed) {
-            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, rope_cos,
+        if (w->packed & 1) {
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV | tf, nullptr, 0, rope_cos,
                                 rope_sin, seq_len, sk, skb, stream));
         } else {
-            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr,
                                 nullptr, 0, sk, skb, stream));
             TRY(llada_rope_bf16(qkv, rope_cos, rope_sin, n_seq, seq_len, c.n_heads, stream));
         }
@@ -177,24 +179,24 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
             al = h;
             hl = hc;
         }
-        TRY(llada_gemm_residual_rmsnorm_bf16(al, w->wo[l], xl, hl, w->ff_norm[l], c.rms_eps, Ml, d, d, d, sk, skb, stream));
-        if (w->packed) {
-            TRY(llada_gemm_bf16(hl, w->wgu[l], act, Ml, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr,
+        TRY(llada_gemm_residual_rmsnorm_bf16(al, w->wo[l], xl, hl, w->ff_norm[l], c.rms_eps, Ml, d, d, d, tl, sk, skb, stream));
+        if (w->packed & 1) {
+            TRY(llada_gemm_bf16(hl, w->wgu[l], act, Ml, 2 * F, d, d, F, LLADA_EPI_SWIGLU | tf, nullptr, 0, nullptr, nullptr,
                                 0, sk, skb, stream));
         } else {
-            TRY(llada_gemm_bf16(hl, w->wgu[l], gu, Ml, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+            TRY(llada_gemm_bf16(hl, w->wgu[l], gu, Ml, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr,
                                 nullptr, 0, sk, skb, stream));
             TRY(llada_swiglu_bf16(gu, act, Ml, F, stream));
         }
         if (!last) {
-            TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], x, h, w->attn_norm[l + 1], c.rms_eps, M, d, F, F, sk,
+            TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], x, h, w->attn_norm[l + 1], c.rms_eps, M, d, F, F, tl, sk,
                                                  skb, stream));
         } else if (prune) {   // the compacted rows are exactly the rows of the final norm
-            TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], xl, hf, w->ln_f, c.rms_eps, Ml, d, F, F, sk, skb,
+            TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], xl, hf, w->ln_f, c.rms_eps, Ml, d, F, F, tl, sk, skb,
                                                  stream));
             final_norm_done = true;
         } else {
-            TRY(llada_gemm_bf16(act, w->wdown[l], xl, Ml, d, F, F, d, LLADA_EPI_RESIDUAL, xl, d, nullptr, nullptr, 0,
+            TRY(llada_gemm_bf16(act, w->wdown[l], xl, Ml, d, F, F, d, LLADA_EPI_RESIDUAL | tf, xl, d, nullptr, nullptr, 0,
                                 sk, skb, stream));
         }
     }
@@ -204,7 +206,7 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
         else
             TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, R, d, c.rms_eps, logit_rows, stream));
     }
-    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, R, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr,
+    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, R, V, d, d, V, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr,
                         nullptr, 0, sk, skb, stream));
     return LLADA_OK;
 }
@@ -244,6 +246,8 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
     void* sk = lay.splitk_bytes ? ws + lay.splitk : nullptr;
     const size_t skb = lay.splitk_bytes;
     const int d = c.d_model, F = c.mlp_hidden, V = c.vocab_size;
+    const int tl = (w->packed & 2) ? 1 : 0;            // projection matrices stored tile-major
+    const int tf = tl ? LLADA_GEMM_W_TILED : 0;
     // rotary tables of the block's positions: row block_start onwards, period block_len
     const float* cos_b = rope_cos + (size_t)block_start * 64;
     const float* sin_b = rope_sin + (size_t)block_start * 64;
@@ -254,11 +258,11 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
     for (int l = 0; l < c.n_layers; ++l) {
         const bool last = l == c.n_layers - 1;
         bf16_t* image = (bf16_t*)((unsigned char*)kv_cache + (size_t)l * M * 3 * d * 2);
-        if (w->packed) {
-            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, Mb, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV, nullptr, 0, cos_b, sin_b,
+        if (w->packed & 1) {
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, Mb, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV | tf, nullptr, 0, cos_b, sin_b,
                                 block_len, sk, skb, stream));
         } else {
-            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, Mb, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN, nullptr, 0, nullptr, nullptr,
+            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, Mb, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr, nullptr,
                                 0, sk, skb, stream));
             TRY(llada_rope_bf16(qkv, cos_b, sin_b, n_seq, block_len, c.n_heads, stream));
         }
@@ -271,20 +275,20 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
         }
         TRY(llada_attn_bidir_queries_bf16(qkv, (int64_t)3 * d, block_len, image, key_mask, att, n_seq, seq_len, c.n_heads,
                                           stream));
-        TRY(llada_gemm_residual_rmsnorm_bf16(att, w->wo[l], x, h, w->ff_norm[l], c.rms_eps, Mb, d, d, d, sk, skb, stream));
-        if (w->packed) {
-            TRY(llada_gemm_bf16(h, w->wgu[l], act, Mb, 2 * F, d, d, F, LLADA_EPI_SWIGLU, nullptr, 0, nullptr, nullptr, 0,
+        TRY(llada_gemm_residual_rmsnorm_bf16(att, w->wo[l], x, h, w->ff_norm[l], c.rms_eps, Mb, d, d, d, tl, sk, skb, stream));
+        if (w->packed & 1) {
+            TRY(llada_gemm_bf16(h, w->wgu[l], act, Mb, 2 * F, d, d, F, LLADA_EPI_SWIGLU | tf, nullptr, 0, nullptr, nullptr, 0,
                                 sk, skb, stream));
         } else {
-            TRY(llada_gemm_bf16(h, w->wgu[l], gu, Mb, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN, nullptr, 0, nullptr, nullptr,
+            TRY(llada_gemm_bf16(h, w->wgu[l], gu, Mb, 2 * F, d, d, 2 * F, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr, nullptr,
                                 0, sk, skb, stream));
             TRY(llada_swiglu_bf16(gu, act, Mb, F, stream));
         }
         TRY(llada_gemm_residual_rmsnorm_bf16(act, w->wdown[l], x, last ? hf : h, last ? w->ln_f : w->attn_norm[l + 1],
-                                             c.rms_eps, Mb, d, F, F, sk, skb, stream));
+                                             c.rms_eps, Mb, d, F, F, tl, sk, skb, stream));
     }
     if (c.n_layers == 0) TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, Mb, d, c.rms_eps, nullptr, stream));
-    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, Mb, V, d, d, V, LLADA_EPI_PLAIN, nullptr, 0, nullptr, nullptr, 0, sk,
+    TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, Mb, V, d, d, V, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr, nullptr, 0, sk,
                         skb, stream));
     return LLADA_OK;
 }

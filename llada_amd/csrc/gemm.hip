@@ -45,6 +45,12 @@ struct GemmParams {
     bf16_t* norm_out;       // [M, N] normalised rows
     float norm_eps;
     int* norm_fused;        // host flag: set to 1 when the second pass produced norm_out
+    // Weight addressing: element (n0 + r, k0 + c) of W, n0 = tn * 256, k0 = kt * 64, is at
+    //   W + tn * w_tile_stride + r * w_row_stride + kt * w_kstride + c.
+    // Row-major [N, K]: (256 K, K, 64).  Tile-major (each 256 x 64 block contiguous, blocks of one
+    // 256-row band consecutive along K): (256 K, 64, 256 * 64).
+    size_t w_tile_stride;
+    int w_row_stride, w_kstride;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -281,8 +287,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
     for (int i = 0; i < B_LOADS; ++i) {
         const int row = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int grow = min(n0 + row, p.N - 1);
-        b_src[i] = p.W + (size_t)grow * p.K + k_first + chunk * 8;
+        const int trow = min(n0 + row, p.N - 1) - n0;
+        b_src[i] = p.W + (size_t)tn * p.w_tile_stride + (size_t)trow * p.w_row_stride +
+                   (k_first / BK) * p.w_kstride + chunk * 8;
     }
 
     auto stage = [&](int s, int kt) {
@@ -290,7 +297,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) glds16(a_src[i] + kt * BK, base + (i * 8 + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) glds16(b_src[i] + kt * BK, base + A_BYTES + (i * 8 + wave) * 1024);
+        for (int i = 0; i < B_LOADS; ++i) glds16(b_src[i] + (size_t)kt * p.w_kstride, base + A_BYTES + (i * 8 + wave) * 1024);
     };
 
     f32x4 acc[MFR][4];
@@ -398,7 +405,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
                 const int rho = g * 8 + (lane >> 3);
                 const int tcol = (rho >> 5) * 64 + h * 32 + (rho & 31);
                 const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-                b_src[h][u] = p.W + (size_t)min(n0 + tcol, p.N - 1) * p.K + k_first + chunk * 8;
+                b_src[h][u] = p.W + (size_t)tn * p.w_tile_stride + (size_t)(min(n0 + tcol, p.N - 1) - n0) * p.w_row_stride +
+                              (k_first / BK) * p.w_kstride + chunk * 8;
             }
         }
 
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
             glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
     };
     auto issue_b = [&](int h, int tt) {
-        const int ks = min(tt, nk - 1) * BK;
+        const size_t ks = (size_t)min(tt, nk - 1) * p.w_kstride;
         unsigned char* base = smem + (tt & 1) * STAGE + 2 * AH_BYTES + h * BH_BYTES;
         glds16(b_src[h][0] + ks, base + wave * 1024);
         glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
@@ -596,7 +604,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_stream_kernel(const Gem
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 a_src[h][u] = p.A + (size_t)min(m0 + a_trow[h][u], p.M - 1) * p.lda + k_first + a_chunk[u];
-                b_src[h][u] = p.W + (size_t)min(n0 + b_tcol[h][u], p.N - 1) * p.K + k_first + b_chunk[u];
+                b_src[h][u] = p.W + (size_t)(n0 / BN) * p.w_tile_stride +
+                              (size_t)(min(n0 + b_tcol[h][u], p.N - 1) - n0) * p.w_row_stride +
+                              (k_first / BK) * p.w_kstride + b_chunk[u];
             }
     };
 
@@ -611,7 +621,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_stream_kernel(const Gem
             glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
     };
     auto issue_b = [&](int h, int kt, int par) {
-        const int ks = min(kt, nk - 1) * BK;
+        const size_t ks = (size_t)min(kt, nk - 1) * p.w_kstride;
         unsigned char* base = smem + par * STAGE + 2 * AH_BYTES + h * BH_BYTES;
         glds16(b_src[h][0] + ks, base + wave * 1024);
         glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
@@ -889,7 +899,7 @@ int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel, 2 
 int g_stream_grid = 256;  // workgroups of the persistent kernel (one per CU)
 int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
 int g_force_splits = 0;   // test hook: > 0 forces the split count when a workspace is given
-size_t g_slab_bytes = 0;  // capacity of the caller's split-K workspace for the current call
+thread_local size_t g_slab_bytes = 0;  // capacity of the caller's split-K workspace for the current call
 
 // Split count for a launch that would leave CUs idle: estimated time = rounds * (fill/drain +
 // K steps) + the reduce pass, in microseconds at ~1.25 us per K step.
@@ -982,6 +992,13 @@ int launch(const GemmParams& p, hipStream_t stream) {
     q.tiles_n = (p.N + BN - 1) / BN;
     q.n_tiles = q.tiles_m * q.tiles_n;
     const int nk_total = p.K / BK;
+    q.w_tile_stride = (size_t)BN * p.K;
+    if (p.w_row_stride == BK) {   // tile-major weights (the entry point checked N % 256 == 0)
+        q.w_kstride = BN * BK;
+    } else {
+        q.w_row_stride = p.K;
+        q.w_kstride = BK;
+    }
     q.splits = pick_splits(q.n_tiles, nk_total, p.M, p.N, MFR != 8 && g_use_pipelined);
     if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
     const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
@@ -1047,6 +1064,8 @@ extern "C" void llada_gemm_use_pipelined(int on) { g_use_pipelined = on; }
 extern "C" void llada_gemm_stream_grid(int n) { g_stream_grid = n > 0 ? (n & ~7) > 0 ? (n & ~7) : 8 : 256; }
 extern "C" void llada_gemm_force_splits(int splits) { g_force_splits = splits; }
 extern "C" void llada_gemm_no_store(int on) { g_no_store = on; }
+static int g_w_tiled = 0;  // timing hook: address W as tile-major whatever the caller says (results are garbage)
+extern "C" void llada_gemm_assume_tiled(int on) { g_w_tiled = on; }
 
 extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
     g_band_m = band_m > 0 ? band_m : 8;
@@ -1121,6 +1140,9 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     LLADA_CHECK_SUPPORTED(M < (1ll << 31), "gemm: M too large");
     LLADA_CHECK_ARG(lda >= K && (lda % 8) == 0, "gemm: lda=%d must be >= K and a multiple of 8", lda);
     LLADA_CHECK_ARG((ldc % 8) == 0 && ((uintptr_t)C & 15) == 0, "gemm: ldc=%d must be a multiple of 8 and C 16-byte aligned", ldc);
+    const bool w_tiled = (epilogue & LLADA_GEMM_W_TILED) != 0;
+    epilogue &= ~LLADA_GEMM_W_TILED;
+    LLADA_CHECK_SUPPORTED(!w_tiled || N % BN == 0, "gemm: tile-major weights need N=%d to be a multiple of %d", N, BN);
     GemmParams p{};
     p.A = (const bf16_t*)A;
     p.W = (const bf16_t*)W;
@@ -1137,6 +1159,7 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     p.seq_len = seq_len;
     p.slab = (float*)workspace;
     p.splits = 1;
+    if (w_tiled || (g_w_tiled && N % BN == 0)) p.w_row_stride = BK;
     g_slab_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
     const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
@@ -1177,7 +1200,8 @@ static int gemm_dispatch(GemmParams& p, int epilogue, int mfr, const void* aux, 
 // this is llada_gemm_bf16(EPI_RESIDUAL) followed by llada_rmsnorm_bf16.  Bit-identical either way.
 extern "C" int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, void* X, void* H, const void* norm_w,
                                                 float eps, int64_t M, int32_t N, int32_t K, int32_t lda,
-                                                void* workspace, size_t workspace_bytes, void* stream) {
+                                                int32_t w_tiled, void* workspace, size_t workspace_bytes,
+                                                void* stream) {
     LLADA_CHECK_ARG(A && W && X && H && norm_w, "gemm_residual_rmsnorm: null operand");
     LLADA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_residual_rmsnorm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     LLADA_CHECK_SUPPORTED(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
@@ -1187,6 +1211,7 @@ extern "C" int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, vo
                     "gemm_residual_rmsnorm: operands must be 16-byte aligned");
     LLADA_CHECK_SUPPORTED(M < (1ll << 31), "gemm: M too large");
     LLADA_CHECK_ARG(lda >= K && (lda % 8) == 0, "gemm: lda=%d must be >= K and a multiple of 8", lda);
+    LLADA_CHECK_SUPPORTED(!w_tiled || N % BN == 0, "gemm: tile-major weights need N=%d to be a multiple of %d", N, BN);
     GemmParams p{};
     p.A = (const bf16_t*)A;
     p.W = (const bf16_t*)W;
@@ -1205,6 +1230,7 @@ extern "C" int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, vo
     p.norm_out = (bf16_t*)H;
     p.norm_eps = eps;
     p.norm_fused = &fused;
+    if (w_tiled || (g_w_tiled && N % BN == 0)) p.w_row_stride = BK;
     g_slab_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
     const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);

@@ -32,7 +32,7 @@ class LLaDAModel:
 
         w = weights
         self._arrays = [arr(w.attn_norm), arr(w.wqkv), arr(w.wo), arr(w.ff_norm), arr(w.wgu), arr(w.wdown)]
-        self._c_w = _lib.Weights(1 if w.packed else 0, w.wte.data_ptr(), w.ln_f.data_ptr(), w.lm_head.data_ptr(),
+        self._c_w = _lib.Weights((1 if w.packed else 0) | (2 if w.tiled else 0), w.wte.data_ptr(), w.ln_f.data_ptr(), w.lm_head.data_ptr(),
                                  *[C.cast(a, C.POINTER(C.c_void_p)) for a in self._arrays])
         self._ws = None
         self._ws_block = None

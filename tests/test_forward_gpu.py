@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def build(ocfg, W, packed=True):
+def build(ocfg, W, packed=True, tiled=None):
     from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights
     cfg = LLaDAConfig(d_model=ocfg.d_model, n_layers=ocfg.n_layers, n_heads=ocfg.n_heads, mlp_hidden=ocfg.mlp_hidden,
                       vocab_size=ocfg.vocab_size, rope_theta=ocfg.rope_theta, rms_eps=ocfg.rms_eps)
-    return LLaDAModel(LLaDAWeights.from_numpy(cfg, W, "cuda", packed=packed))
+    return LLaDAModel(LLaDAWeights.from_numpy(cfg, W, "cuda", packed=packed, tiled=tiled))
 
 
 @pytest.fixture(scope="module")
@@ -49,6 +49,19 @@ def test_forward_logits(lib, tiny, packed):
         ref = forward(W, ocfg, z["ids"], mask, emulate_bf16=True)
         assert max_rel(got, ref) <= 2e-2, max_rel(got, ref)        # contract: bf16 tolerance, max rel 2e-2
         assert max_rel(got, z[key]) <= 2e-2, max_rel(got, z[key])  # and against the float32 stand-in itself
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_forward_tile_major_weights_are_bit_identical(lib, tiny, packed):
+    """Storing the projection matrices tile-major only changes where the GEMMs read them from."""
+    z, ocfg, W = tiny
+    a, b = build(ocfg, W, packed, tiled=False), build(ocfg, W, packed, tiled=True)
+    assert b.weights.tiled and not a.weights.tiled
+    ids = torch.from_numpy(z["ids"]).cuda()
+    am = torch.from_numpy(z["key_mask"]).cuda()
+    assert torch.equal(a(ids, attention_mask=am).logits, b(ids, attention_mask=am).logits)
+    rows = torch.tensor([3, 17, 40], dtype=torch.int32, device="cuda")
+    assert torch.equal(a.forward_rows(ids, None, rows), b.forward_rows(ids, None, rows))
 
 
 def test_forward_row_subset_is_exact(lib, tiny):

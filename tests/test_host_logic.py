@@ -72,3 +72,21 @@ def test_shard_bounds():
 def test_config_counts():
     from llada_amd import LLaDAConfig
     assert LLaDAConfig().linear_params() == 7497318400
+
+
+def test_tile_major_layout_roundtrip_and_index_formula():
+    """weights.tile_major: element (n, k) of an [N, K] matrix moves to
+    ((n // 256 * (K // 64) + k // 64) * 256 + n % 256) * 64 + k % 64 (what LLADA_GEMM_W_TILED addresses)."""
+    import torch
+
+    from llada_amd.weights import LLaDAConfig, can_tile, from_tile_major, tile_major
+    N, K = 512, 192
+    w = torch.arange(N * K, dtype=torch.int32).reshape(N, K)
+    t = tile_major(w)
+    assert t.shape == w.shape and torch.equal(from_tile_major(t), w)
+    flat = t.reshape(-1)
+    for n, k in ((0, 0), (1, 0), (0, 64), (255, 63), (256, 0), (300, 130), (511, 191)):
+        at = ((n // 256 * (K // 64) + k // 64) * 256 + n % 256) * 64 + k % 64
+        assert int(flat[at]) == n * K + k
+    assert can_tile(LLaDAConfig()) and can_tile(LLaDAConfig(d_model=256, n_heads=2, mlp_hidden=512, vocab_size=512))
+    assert not can_tile(LLaDAConfig(d_model=256, n_heads=2, mlp_hidden=192, vocab_size=512))

@@ -245,17 +245,68 @@ def test_gemm_residual_rmsnorm_fused(lib, M, N, K, splits):
         X2 = X0.clone()
         H2 = torch.full_like(X2, float("nan"))
         check(lib, lib.llada_gemm_residual_rmsnorm_bf16(A.data_ptr(), W.data_ptr(), X2.data_ptr(), H2.data_ptr(),
-                                                        nw.data_ptr(), eps, M, N, K, K, ws.data_ptr(), ws.numel(),
+                                                        nw.data_ptr(), eps, M, N, K, K, 0, ws.data_ptr(), ws.numel(),
+                                                        stream()))
+        # the same with the weight stored tile-major
+        from llada_amd.weights import tile_major
+        Wt = tile_major(W)
+        X3 = X0.clone()
+        H3 = torch.full_like(X3, float("nan"))
+        check(lib, lib.llada_gemm_residual_rmsnorm_bf16(A.data_ptr(), Wt.data_ptr(), X3.data_ptr(), H3.data_ptr(),
+                                                        nw.data_ptr(), eps, M, N, K, K, 1, ws.data_ptr(), ws.numel(),
                                                         stream()))
         torch.cuda.synchronize()
     finally:
         lib.llada_gemm_force_splits(0)
     assert torch.equal(X1, X2) and torch.equal(H1, H2)
+    assert torch.equal(X1, X3) and torch.equal(H1, H3)
     x = host(X2)
     # two roundings (x * rstd, then * w): a 1-ulp difference of the first can move the second by one more
     ref_h = omodel.rmsnorm(x, host(nw), eps, True)
     ud = ulp_distance(host(H2), ref_h)
     assert ud.max() <= 2 and (ud <= 1).mean() >= 0.999
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("tile_rows", [128, 192, 256])
+@pytest.mark.parametrize("M,N,K,splits", [(300, 512, 256, 0), (1000, 768, 512, 0), (64, 1024, 1024, 4), (37, 256, 64, 0),
+                                          (640, 2048, 384, 2)])
+def test_gemm_tile_major_weights(lib, M, N, K, splits, tile_rows, mode):
+    """Tile-major weight storage is a pure change of addressing: every main loop (simple, pipelined,
+    persistent), tile height and split count gives the row-major result bit for bit."""
+    from llada_amd.weights import tile_major
+    g = np.random.Generator(np.random.PCG64(M * 7 + N + K))
+    A = bf(g.standard_normal((M, K), dtype=np.float32))
+    W = bf(g.standard_normal((N, K), dtype=np.float32) * 0.05)
+    Wt = tile_major(W)
+    ws = torch.empty(16 * M * N * 4, dtype=torch.uint8, device="cuda")
+    lib.llada_gemm_force_tile_rows(tile_rows)
+    lib.llada_gemm_use_pipelined(mode)
+    lib.llada_gemm_force_splits(splits)
+    try:
+        out = []
+        for w, flag in ((W, 0), (Wt, 0x100)):
+            Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            check(lib, lib.llada_gemm_bf16(A.data_ptr(), w.data_ptr(), Cc.data_ptr(), M, N, K, K, N, 0 | flag, None, 0,
+                                           None, None, 0, ws.data_ptr(), ws.numel(), stream()))
+            out.append(Cc)
+        torch.cuda.synchronize()
+    finally:
+        lib.llada_gemm_force_tile_rows(0)
+        lib.llada_gemm_use_pipelined(1)
+        lib.llada_gemm_force_splits(0)
+    assert torch.equal(out[0], out[1])
+    ref = host(A) @ host(W).T
+    assert np.abs(host(out[1]) - ref).max() <= 2e-2 * np.abs(ref).max()
+
+
+def test_gemm_tile_major_rejects_ragged_n(lib):
+    A = torch.zeros((16, 64), dtype=torch.bfloat16, device="cuda")
+    W = torch.zeros((264, 64), dtype=torch.bfloat16, device="cuda")
+    Cc = torch.zeros((16, 264), dtype=torch.bfloat16, device="cuda")
+    rc = lib.llada_gemm_bf16(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), 16, 264, 64, 64, 264, 0x100, None, 0, None, None,
+                             0, None, 0, stream())
+    assert rc == -2 and b"tile-major" in lib.llada_last_error()
 
 
 def test_gemm_rope_epilogue(lib):
