@@ -177,7 +177,12 @@ int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, void* out, i
  * head h at columns h*128) over all seq_len keys/values of a [Q | K | V] image kv [n_seq*seq_len, 3*d];
  * out [n_seq*n_q, d].  Used by the block-cached sampler (llada_forward_block). */
 int llada_attn_bidir_queries_bf16(const void* q, int64_t q_stride, int32_t n_q, const void* kv, const uint8_t* key_mask,
-                                  void* out, int32_t n_seq, int32_t seq_len, int32_t n_heads, void* stream);
+                                  void* out, int32_t n_seq, int32_t seq_len, int32_t n_heads, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+/* Float32 scratch for the call above (workspace may be NULL): with it, when n_seq * n_heads * ceil(n_q / 128)
+ * workgroups would leave most CUs idle, the keys are cut into runs of 64-key tiles, one workgroup each, whose
+ * unnormalised partial results a second kernel merges (same softmax, different summation order). */
+size_t llada_attn_workspace_bytes(int32_t n_seq, int32_t n_q, int32_t seq_len, int32_t n_heads);
 
 /* ---------------------------------------------------------------------------------------------
  * Block-cached forward.  No counterpart in the reference, whose sampler recomputes every position at
@@ -195,7 +200,7 @@ int llada_forward_fill_cache(const llada_config* cfg, const llada_weights* w, co
                              const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                              int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out,
                              void* workspace, size_t workspace_bytes, void* kv_cache, void* stream);
-size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t block_len);
+size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len, int32_t block_len);
 int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
                         const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                         int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache, void* logits_out,

@@ -60,11 +60,13 @@ SIGNATURES = {
     "llada_rope_bf16": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
     "llada_swiglu_bf16": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp]),
     "llada_attn_bidir_bf16": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
-    "llada_attn_bidir_queries_bf16": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "llada_attn_bidir_queries_bf16": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp,
+                                                C.c_size_t, vp]),
+    "llada_attn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "llada_kv_cache_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32]),
     "llada_forward_fill_cache": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32, vp,
                                            C.c_int32, vp, vp, C.c_size_t, vp, vp]),
-    "llada_forward_block_workspace_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32]),
+    "llada_forward_block_workspace_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32]),
     "llada_forward_block": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
     "llada_num_transfer_tokens": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
@@ -78,7 +80,7 @@ SIGNATURES = {
 }
 # test hooks outside the public header
 _EXTRA = {"llada_gemm_force_tile_rows": (None, [C.c_int]), "llada_gemm_use_pipelined": (None, [C.c_int]),
-          "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_stream_grid": (None, [C.c_int]), "llada_attn_force_variant": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]),
+          "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_stream_grid": (None, [C.c_int]), "llada_attn_force_variant": (None, [C.c_int]), "llada_attn_force_key_splits": (None, [C.c_int]), "llada_gemm_assume_tiled": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]),
           "llada_gemm_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_longlong]),
           "llada_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)])}
 

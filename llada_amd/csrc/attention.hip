@@ -35,20 +35,30 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
 }
 
-template <int NW>
+// SPLIT: blockIdx.z = sequence * key_splits + split; the workgroup sweeps only its own run of key tiles and
+// leaves an unnormalised partial result (float32 O, running max in the log2 domain, row sum) for
+// attn_combine_kernel.  Used when there are too few (query block, head, sequence) triples to fill the chip.
+// MODE 0: the whole key range; 1 = SPLIT; 2 = SPLIT with one tile per run (a single K/V buffer, so that four
+// one-wave workgroups fit in a CU's LDS).
+template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1))
 attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, const bf16_t* __restrict__ kv_src,
                       int64_t kv_stride, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out, int L, int d,
-                      float scale_log2e) {
+                      float scale_log2e, int key_splits, int tiles_per_split, float* __restrict__ part_o,
+                      float* __restrict__ part_ml, int64_t n_rows) {
+    constexpr bool SPLIT = MODE != 0;
+    constexpr int NBUF = MODE == 2 ? 1 : 2;
     constexpr int TILE_BYTES = KT * 256;           // one operand, one tile
     constexpr int BUF_BYTES = 2 * TILE_BYTES;      // K then V
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES + 2 * KT * 4];
-    float* bias_lds = (float*)(lds + 2 * BUF_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF_BYTES + NBUF * KT * 4];
+    float* bias_lds = (float*)(lds + NBUF * BUF_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hg = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int b = SPLIT ? blockIdx.z / key_splits : blockIdx.z;
+    const int ks = SPLIT ? blockIdx.z % key_splits : 0;
     const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     // queries: n_q rows per sequence (row stride q_stride, head h at column h * HD); keys and values: L rows per
     // sequence of a [.. | K | V] image (row stride kv_stride, K at column d, V at column 2 d)
@@ -83,9 +93,11 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
         }
     };
 
-    const int n_tiles = (L + KT - 1) / KT;
-    issue_tile(0, 0);
-    write_bias(0, 0);
+    const int n_tiles_all = (L + KT - 1) / KT;
+    const int t_begin = SPLIT ? ks * tiles_per_split : 0;
+    const int n_tiles = SPLIT ? min(n_tiles_all, t_begin + tiles_per_split) : n_tiles_all;   // one past the last tile
+    issue_tile(t_begin * KT, 0);
+    write_bias(t_begin * KT, 0);
 
     // Q fragments: B operand of S^T = K Q^T, lane holds Q[q0 + r][16*ds + 8*hg .. +7]
     bf16x8 qf[8];
@@ -110,13 +122,15 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
     const int v_row_off = (4 * hg + q4) * 256 + 32 * g1 + 8 * p4;  // + key block; (row & 3) == q4
     const int v_xor = q4 * 64;
 
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
+    for (int t = t_begin; t < n_tiles; ++t) {
+        const int buf = (t - t_begin) & (NBUF - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t (and Q) have landed
         __syncthreads();                                    // ... everyone's; and tile t-1 is no longer read
-        if (t + 1 < n_tiles) {
-            issue_tile((t + 1) * KT, buf ^ 1);
-            write_bias((t + 1) * KT, buf ^ 1);
+        if constexpr (NBUF == 2) {
+            if (t + 1 < n_tiles) {
+                issue_tile((t + 1) * KT, buf ^ 1);
+                write_bias((t + 1) * KT, buf ^ 1);
+            }
         }
         const unsigned char* k_lds = lds + buf * BUF_BYTES;
         const unsigned char* v_lds = k_lds + TILE_BYTES;
@@ -196,8 +210,25 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
     const int q = q0 + r;
+    if constexpr (SPLIT) {
+        if (q < n_q) {
+            const size_t row = (size_t)b * n_q + q;
+            float* po = part_o + ((size_t)ks * n_rows + row) * d + (size_t)h * HD + 4 * hg;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *(f32x4*)(po + db * 32 + 8 * c) = (f32x4){o[db][4 * c], o[db][4 * c + 1], o[db][4 * c + 2], o[db][4 * c + 3]};
+            if (hg == 0) {
+                float* pm = part_ml + (((size_t)ks * n_rows + row) * (d / HD) + h) * 2;
+                pm[0] = m_run;
+                pm[1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
     if (q < n_q) {
         bf16_t* op = out + ((size_t)b * n_q + q) * d + (size_t)h * HD + 4 * hg;
 #pragma unroll
@@ -213,22 +244,87 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
     }
 }
 
+// Merges the key-split partial results: out = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s, m = max_s m_s.
+// One thread per 4 output columns.
+__global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                           bf16_t* __restrict__ out, int64_t n_rows, int H, int key_splits) {
+    const int d = H * HD;
+    const int64_t total = n_rows * (d / 4);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / (d / 4);
+        const int col = (int)(i % (d / 4)) * 4;
+        const int h = col / HD;
+        float m = -INFINITY;
+        for (int s = 0; s < key_splits; ++s) m = fmaxf(m, part_ml[((s * n_rows + row) * H + h) * 2]);
+        const float m_use = (m == -INFINITY) ? 0.f : m;
+        float l = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < key_splits; ++s) {
+            const float* pm = part_ml + ((s * n_rows + row) * H + h) * 2;
+            const float w = __builtin_amdgcn_exp2f(pm[0] - m_use);
+            const f32x4 o = *(const f32x4*)(part_o + (s * n_rows + row) * d + col);
+            l += w * pm[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w * o[e];
+        }
+        const float inv = 1.0f / l;
+        u32x2 w2;
+        w2[0] = pack_bf16x2(acc[0] * inv, acc[1] * inv);
+        w2[1] = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+        *(u32x2*)(out + row * d + col) = w2;
+    }
+}
+
 template <int NW>
 void launch_attn(const bf16_t* q, int64_t q_stride, int n_q, const bf16_t* kv, int64_t kv_stride, const uint8_t* key_mask,
-                 bf16_t* out, int n_seq, int L, int H, int d, float scale, hipStream_t stream) {
+                 bf16_t* out, int n_seq, int L, int H, int d, float scale, int key_splits, int tiles_per_split,
+                 float* part_o, float* part_ml, hipStream_t stream) {
+    const int64_t n_rows = (int64_t)n_seq * n_q;
+    if (key_splits > 1) {
+        dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq * key_splits);
+        if (tiles_per_split == 1)
+            hipLaunchKernelGGL((attn_bidir_kernel<NW, 2>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
+                               key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows);
+        else
+            hipLaunchKernelGGL((attn_bidir_kernel<NW, 1>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
+                               key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows);
+        const int64_t items = n_rows * (d / 4);
+        const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(cgrid), dim3(256), 0, stream, (const float*)part_o,
+                           (const float*)part_ml, out, n_rows, H, key_splits);
+        return;
+    }
     dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq);
-    hipLaunchKernelGGL((attn_bidir_kernel<NW>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride, key_mask,
-                       out, L, d, scale);
+    hipLaunchKernelGGL((attn_bidir_kernel<NW, 0>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
+                       key_mask, out, L, d, scale, 1, 0, (float*)nullptr, (float*)nullptr, n_rows);
 }
 
 int g_attn_variant = 0;   // test hook: waves per workgroup (1, 2, 4), 0 = automatic
+int g_attn_key_splits = 0;  // test hook: 0 = automatic, 1 = never split, n = split the keys n ways when scratch is given
+
+// Key splits for a launch that would put `wgs` workgroups on the 256 CUs: about 512 workgroups in all
+// (measured at 32 queries x 384 keys: 23 -> 12 us for one sequence, 24 -> 19 us for eight; beyond that the
+// merge pass and the extra partial results cost more than the parallelism gains).
+int pick_key_splits(int64_t wgs, int n_tiles) {
+    const int cap = n_tiles < 16 ? n_tiles : 16;
+    if (g_attn_key_splits > 0) return g_attn_key_splits < cap ? g_attn_key_splits : cap;
+    if (wgs > 256 || n_tiles < 2) return 1;
+    const int64_t want = 512 / wgs;
+    return (int)(want < cap ? want : cap);
+}
+
+size_t attn_scratch_bytes(int64_t n_rows, int H, int key_splits) {
+    return (size_t)key_splits * n_rows * ((size_t)H * HD * 4 + (size_t)H * 8);
+}
 
 }  // namespace
 
 extern "C" void llada_attn_force_variant(int v) { g_attn_variant = v; }
+extern "C" void llada_attn_force_key_splits(int n) { g_attn_key_splits = n; }
 
 static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16_t* kvp, int64_t kv_stride,
-                         const uint8_t* key_mask, bf16_t* op, int n_seq, int seq_len, int n_heads, hipStream_t st) {
+                         const uint8_t* key_mask, bf16_t* op, int n_seq, int seq_len, int n_heads, void* scratch,
+                         size_t scratch_bytes, hipStream_t st) {
     const int d = n_heads * HD;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     // Waves per workgroup: 4 (128 queries), fewer when a sequence has fewer queries than that.  More waves per
@@ -236,10 +332,26 @@ static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16
     // every benchmark shape: the per-tile barrier phase-locks the waves that share a SIMD.
     const int q_waves = (n_q + 31) / 32;
     const int nw = g_attn_variant > 0 ? g_attn_variant : (q_waves >= 4 ? 4 : (q_waves >= 2 ? 2 : 1));
+    // Few queries (the block-cached step): cut the keys into runs of tiles, one workgroup each, and merge.
+    int key_splits = 1, tiles_per = 0;
+    float *part_o = nullptr, *part_ml = nullptr;
+    if (scratch) {
+        const int n_tiles = (seq_len + KT - 1) / KT;
+        const int64_t wgs = (int64_t)((n_q + nw * 32 - 1) / (nw * 32)) * n_heads * n_seq;
+        int want = pick_key_splits(wgs, n_tiles);
+        const int64_t n_rows = (int64_t)n_seq * n_q;
+        while (want > 1 && attn_scratch_bytes(n_rows, n_heads, want) > scratch_bytes) --want;
+        if (want > 1 && (int64_t)n_seq * want <= 65535) {
+            tiles_per = (n_tiles + want - 1) / want;
+            key_splits = (n_tiles + tiles_per - 1) / tiles_per;   // no empty run
+            part_o = (float*)scratch;
+            part_ml = part_o + (size_t)key_splits * n_rows * d;
+        }
+    }
     switch (nw) {
-        case 4: launch_attn<4>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        case 2: launch_attn<2>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
-        default: launch_attn<1>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, st); break;
+        case 4: launch_attn<4>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, st); break;
+        case 2: launch_attn<2>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, st); break;
+        default: launch_attn<1>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, st); break;
     }
     LLADA_CHECK_LAUNCH("attn_bidir_kernel");
     return LLADA_OK;
@@ -252,20 +364,30 @@ extern "C" int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, v
     LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
     const int64_t stride = (int64_t)3 * n_heads * HD;
     return attn_dispatch((const bf16_t*)qkv, stride, seq_len, (const bf16_t*)qkv, stride, key_mask, (bf16_t*)out, n_seq,
-                         seq_len, n_heads, (hipStream_t)stream);
+                         seq_len, n_heads, nullptr, 0, (hipStream_t)stream);
 }
 
 // Attention of a subset of the positions: n_q query rows per sequence (q [n_seq * n_q, q_stride], head h at column
 // h * 128) over all seq_len keys and values of a [Q | K | V] image kv [n_seq * seq_len, 3 d] (the per-layer cache of
-// the block-cached sampler).  out [n_seq * n_q, d].
+// the block-cached sampler).  out [n_seq * n_q, d].  With a workspace (llada_attn_workspace_bytes; may be NULL) the
+// keys are split over several workgroups when the queries alone would leave most CUs idle.
+extern "C" size_t llada_attn_workspace_bytes(int32_t n_seq, int32_t n_q, int32_t seq_len, int32_t n_heads) {
+    if (n_seq <= 0 || n_q <= 0 || seq_len <= 0 || n_heads <= 0) return 0;
+    const int n_tiles = (seq_len + KT - 1) / KT;
+    const int splits = n_tiles < 16 ? n_tiles : 16;
+    return splits > 1 ? attn_scratch_bytes((int64_t)n_seq * n_q, n_heads, splits) : 0;
+}
+
 extern "C" int llada_attn_bidir_queries_bf16(const void* q, int64_t q_stride, int32_t n_q, const void* kv,
                                              const uint8_t* key_mask, void* out, int32_t n_seq, int32_t seq_len,
-                                             int32_t n_heads, void* stream) {
+                                             int32_t n_heads, void* workspace, size_t workspace_bytes, void* stream) {
     LLADA_CHECK_ARG(q && kv && out, "attn_queries: null operand");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_heads > 0 && n_q > 0, "attn_queries: bad shape");
     LLADA_CHECK_ARG(q_stride >= (int64_t)n_heads * HD && (q_stride % 8) == 0 && ((uintptr_t)q & 15) == 0,
                     "attn_queries: q_stride must cover the heads and keep rows 16-byte aligned");
     LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
+    LLADA_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "attn_queries: workspace must be 16-byte aligned");
     return attn_dispatch((const bf16_t*)q, q_stride, n_q, (const bf16_t*)kv, (int64_t)3 * n_heads * HD, key_mask,
-                         (bf16_t*)out, n_seq, seq_len, n_heads, (hipStream_t)stream);
+                         (bf16_t*)out, n_seq, seq_len, n_heads, workspace, workspace ? workspace_bytes : 0,
+                         (hipStream_t)stream);
 }

@@ -231,11 +231,13 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
     const int64_t Mb = (int64_t)n_seq * block_len;
     const int64_t M = (int64_t)n_seq * seq_len;
     const Layout lay = make_layout(c, Mb, Mb);
-    if (workspace_bytes < lay.total) {
-        llada_set_error("forward_block: workspace has %zu bytes, %zu needed", workspace_bytes, lay.total);
+    const size_t attn_bytes = llada_attn_workspace_bytes(n_seq, block_len, seq_len, c.n_heads);   // key-split partials
+    if (workspace_bytes < lay.total + attn_bytes) {
+        llada_set_error("forward_block: workspace has %zu bytes, %zu needed", workspace_bytes, lay.total + attn_bytes);
         return LLADA_ERR_WORKSPACE;
     }
     unsigned char* ws = (unsigned char*)workspace;
+    void* attn_ws = attn_bytes ? ws + lay.total : nullptr;
     void* x = ws + lay.x;
     void* h = ws + lay.h;
     void* qkv = ws + lay.qkv;
@@ -274,7 +276,7 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
             LLADA_CHECK_LAUNCH("scatter_kv_kernel");
         }
         TRY(llada_attn_bidir_queries_bf16(qkv, (int64_t)3 * d, block_len, image, key_mask, att, n_seq, seq_len, c.n_heads,
-                                          stream));
+                                          attn_ws, attn_bytes, stream));
         TRY(llada_gemm_residual_rmsnorm_bf16(att, w->wo[l], x, h, w->ff_norm[l], c.rms_eps, Mb, d, d, d, tl, sk, skb, stream));
         if (w->packed & 1) {
             TRY(llada_gemm_bf16(h, w->wgu[l], act, Mb, 2 * F, d, d, F, LLADA_EPI_SWIGLU | tf, nullptr, 0, nullptr, nullptr, 0,
@@ -293,8 +295,9 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
     return LLADA_OK;
 }
 
-extern "C" size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t block_len) {
-    if (!cfg || n_seq <= 0 || block_len <= 0) return 0;
+extern "C" size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len,
+                                                      int32_t block_len) {
+    if (!cfg || n_seq <= 0 || block_len <= 0 || seq_len <= 0) return 0;
     const int64_t Mb = (int64_t)n_seq * block_len;
-    return make_layout(*cfg, Mb, Mb).total;
+    return make_layout(*cfg, Mb, Mb).total + llada_attn_workspace_bytes(n_seq, block_len, seq_len, cfg->n_heads);
 }

@@ -813,7 +813,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
         const float* src = p.slab + (size_t)m * p.N + n1;
         f32x4 v1 = *(const f32x4*)src, v2 = {0.f, 0.f, 0.f, 0.f};
         if (PAIRED) v2 = *(const f32x4*)(src + 16);
-        for (int sidx = 1; sidx < p.splits; ++sidx) {
+        // the partial tiles are fetched four at a time (independent loads in flight) and added in split order
+        int sidx = 1;
+        for (; sidx + 3 < p.splits; sidx += 4) {
+            f32x4 t1[4], t2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t1[j] = *(const f32x4*)(src + (sidx + j) * slab_stride);
+                if (PAIRED) t2[j] = *(const f32x4*)(src + (sidx + j) * slab_stride + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v1[e] += t1[j][e];
+                    if (PAIRED) v2[e] += t2[j][e];
+                }
+        }
+        for (; sidx < p.splits; ++sidx) {
             const f32x4 t1 = *(const f32x4*)(src + sidx * slab_stride);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v1[e] += t1[e];
@@ -847,7 +864,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_norm_kernel(const GemmParam
             if (c < chunks) {
                 const float* src = p.slab + (size_t)m * p.N + c * 8;
                 f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
-                for (int sidx = 1; sidx < p.splits; ++sidx) {
+                // four partial tiles per round: independent loads in flight, added in split order
+                int sidx = 1;
+                for (; sidx + 3 < p.splits; sidx += 4) {
+                    f32x4 ta[4], tb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ta[j] = *(const f32x4*)(src + (sidx + j) * slab_stride);
+                        tb[j] = *(const f32x4*)(src + (sidx + j) * slab_stride + 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] += ta[j][e];
+                            b[e] += tb[j][e];
+                        }
+                }
+                for (; sidx < p.splits; ++sidx) {
                     const f32x4 ta = *(const f32x4*)(src + sidx * slab_stride);
                     const f32x4 tb = *(const f32x4*)(src + sidx * slab_stride + 4);
 #pragma unroll

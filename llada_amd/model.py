@@ -86,7 +86,7 @@ class LLaDAModel:
         cos, sin = self.rope_tables(seq_len)
         if out is None:
             out = torch.empty(n_seq * bl, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
-        need = self.lib.llada_forward_block_workspace_bytes(C.byref(self._c_cfg), n_seq, bl)
+        need = self.lib.llada_forward_block_workspace_bytes(C.byref(self._c_cfg), n_seq, seq_len, bl)
         if self._ws_block is None or self._ws_block.numel() < need:
             self._ws_block = None
             self._ws_block = torch.empty(need, dtype=torch.uint8, device=self.device)

@@ -55,7 +55,7 @@ def test_attention_query_subset_is_exact(lib, n_seq, L, H, q0, n_q, masked):
     q = qkv.reshape(n_seq, L, 3 * d)[:, q0:q0 + n_q].contiguous().reshape(n_seq * n_q, 3 * d)
     sub = torch.full((n_seq * n_q, d), float("nan"), dtype=torch.bfloat16, device="cuda")
     assert lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, n_q, qkv.data_ptr(), None if km is None else km.data_ptr(),
-                                             sub.data_ptr(), n_seq, L, H, st) == 0, lib.llada_last_error()
+                                             sub.data_ptr(), n_seq, L, H, None, 0, st) == 0, lib.llada_last_error()
     torch.cuda.synchronize()
     want = full.reshape(n_seq, L, d)[:, q0:q0 + n_q].reshape(n_seq * n_q, d)
     assert torch.equal(sub, want)
@@ -64,9 +64,56 @@ def test_attention_query_subset_is_exact(lib, n_seq, L, H, q0, n_q, masked):
 def test_attention_queries_rejects_bad_arguments(lib):
     t = torch.zeros((64, 384), dtype=torch.bfloat16, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 64, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, st) == -1
-    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 384, 0, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, st) == -1
-    assert lib.llada_attn_bidir_queries_bf16(None, 384, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, st) == -1
+    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 64, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, st) == -1
+    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 384, 0, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, st) == -1
+    assert lib.llada_attn_bidir_queries_bf16(None, 384, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, st) == -1
+
+
+@pytest.mark.parametrize("splits", [0, 2, 3, 16])
+@pytest.mark.parametrize("n_seq,L,H,q0,n_q,masked", [(1, 384, 2, 128, 32, False), (2, 384, 2, 352, 32, True),
+                                                     (2, 1152, 1, 128, 128, True), (1, 200, 2, 60, 70, True),
+                                                     (8, 384, 4, 160, 32, False)])
+def test_attention_key_split(lib, n_seq, L, H, q0, n_q, masked, splits):
+    """Few queries over many keys (the block-cached step): the keys are cut into runs of tiles, one workgroup
+    each, and a second kernel merges the partial softmaxes.  Same result as the one-pass kernel up to the
+    float32 summation order (checked to one bf16 step of the largest output) and within the attention
+    tolerance of the oracle; includes a run of keys that is masked out entirely."""
+    from oracle.model import attention as oattn
+    d = H * 128
+    g = np.random.Generator(np.random.PCG64(L + n_q + splits))
+    qkv_n = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
+    qkv_n[L // 2, d:2 * d] *= 4
+    qkv = torch.from_numpy(qkv_n).cuda().to(torch.bfloat16)
+    km = kmn = None
+    if masked:
+        kmn = np.ones((n_seq, L), dtype=np.uint8)
+        kmn[:, :70] = 0                    # the whole first 64-key tile (a split with nothing to attend)
+        kmn[n_seq - 1, 100:131] = 0
+        km = torch.from_numpy(kmn).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    q = qkv.reshape(n_seq, L, 3 * d)[:, q0:q0 + n_q].contiguous().reshape(n_seq * n_q, 3 * d)
+    kmp = None if km is None else km.data_ptr()
+    one = torch.full((n_seq * n_q, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    assert lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, n_q, qkv.data_ptr(), kmp, one.data_ptr(), n_seq, L, H,
+                                             None, 0, st) == 0, lib.llada_last_error()
+    need = lib.llada_attn_workspace_bytes(n_seq, n_q, L, H)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    two = torch.full((n_seq * n_q, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lib.llada_attn_force_key_splits(splits)
+    try:
+        assert lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, n_q, qkv.data_ptr(), kmp, two.data_ptr(), n_seq, L,
+                                                 H, ws.data_ptr(), ws.numel(), st) == 0, lib.llada_last_error()
+        torch.cuda.synchronize()
+    finally:
+        lib.llada_attn_force_key_splits(0)
+    a, b = one.float().cpu().numpy(), two.float().cpu().numpy()
+    assert np.isfinite(b).all()
+    assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(a).max()
+    x = qkv_n.reshape(n_seq, L, 3, H, 128)
+    qq, kk, vv = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    ref = oattn(qq[:, :, q0:q0 + n_q], kk, vv, kmn, False).transpose(0, 2, 1, 3).reshape(n_seq * n_q, d)
+    assert np.abs(b - ref).max() <= 1.5e-2 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("packed", [True, False])
