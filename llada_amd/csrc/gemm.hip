@@ -963,7 +963,7 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     constexpr int BM = MFR * 32;
     constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
     const int nk = q.K / BK / q.splits;
-    if constexpr (MFR != 8) {  // the 256-row tile does not fit the pipelined kernel's register budget
+    if constexpr (MFR != 8) {  // the persistent form of the 256-row tile spills registers
         // The persistent form pays off where a workgroup gets several tiles and the write-out issues no
         // loads of its own (gate/up projection: 6 tiles per CU at M = 3072); elsewhere it is neutral or
         // slower in situ.  Hook values: 2 = always, 3 = never.
@@ -985,6 +985,8 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
             LLADA_CHECK_LAUNCH("gemm_bf16_stream_kernel");
             return LLADA_OK;
         }
+    }
+    {
         if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
             static OncePerDevice attr2_set;
             if (attr2_set.first()) {
@@ -1033,7 +1035,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
         q.w_row_stride = p.K;
         q.w_kstride = BK;
     }
-    q.splits = pick_splits(q.n_tiles, nk_total, p.M, p.N, MFR != 8 && g_use_pipelined);
+    q.splits = pick_splits(q.n_tiles, nk_total, p.M, p.N, g_use_pipelined != 0);
     if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
     const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
     if (rc != LLADA_OK) return rc;
@@ -1056,10 +1058,12 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return LLADA_OK;
 }
 
-// Pick the M tile (128 / 192 / 256 rows) that wastes the least work: padded rows plus the idle
-// CUs of the last, partially filled round of tiles over the 256 CUs, times a per-tile efficiency
-// factor (measured: the 128- and 192-row pipelined loops run at the same rate per row within a few
-// percent; 256 rows only has the simple two-stage loop).
+// Pick the M tile (128 / 192 / 256 rows): estimated time = rounds of tiles over the 256 CUs x rows per
+// tile x a per-row efficiency factor.  A last round that is only partly filled still takes most of a round
+// (a tile needs its full latency; measured ~0.8 of one).  Factors from measurements at K = 4096: the 256-row
+// pipelined loop moves 14 % fewer operand bytes per FLOP and runs ~4 % faster per row than the 192-row one
+// when its tile count fills the rounds (M = 5120: QKV 353 vs 411 us, gate/up 705 vs 759 us); the 128-row
+// loop is ~3 % slower per row.
 int pick_mfr(int64_t M, int N, int K) {
     (void)K;
     const int cands[3] = {8, 6, 4};
@@ -1070,8 +1074,8 @@ int pick_mfr(int64_t M, int N, int K) {
         const int bm = c * 32;
         const int64_t tiles_m = (M + bm - 1) / bm;
         const int64_t nt = tiles_m * tiles_n;
-        const int64_t rounds = (nt + 255) / 256;
-        const double cost = (double)rounds * bm * (c == 8 ? 1.10 : (c == 6 ? 1.0 : 1.02));
+        const double rounds = (double)(nt / 256) + ((nt % 256) ? 0.8 : 0.0);
+        const double cost = rounds * bm * (c == 8 ? 0.96 : (c == 6 ? 1.0 : 1.03));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;

@@ -67,7 +67,7 @@ def test_gemm_exact_integers(lib, shape, tile_rows):
     assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("tile_rows", [128, 192])
+@pytest.mark.parametrize("tile_rows", [128, 192, 256])
 def test_gemm_pipelined_equals_simple(lib, tile_rows):
     """The quarter-tile pipelined main loop, its persistent form (several tiles per workgroup as one
     continuous K stream; 8 and 24 workgroups over ~28-32 tiles) and the simple two-stage loop

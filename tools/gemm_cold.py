@@ -17,7 +17,7 @@ for M in Ms:
         Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ws = torch.empty(16 * M * N, dtype=torch.float32, device="cuda")
         out = []
-        for rows in (128, 192):
+        for rows in (128, 192, 256):
             for S in (0, 1, 2, 3, 4, 6, 8, 12, 16):
                 if S > 1 and (K // 64) % S: continue
                 lib.llada_gemm_force_tile_rows(rows); lib.llada_gemm_force_splits(S if S else 0); ts = []
