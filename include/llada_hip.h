@@ -175,10 +175,12 @@ int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, void* out, i
 
 /* The same attention for a subset of the positions: q [n_seq*n_q, q_stride] (n_q query rows per sequence,
  * head h at columns h*128) over all seq_len keys/values of a [Q | K | V] image kv [n_seq*seq_len, 3*d];
- * out [n_seq*n_q, d].  Used by the block-cached sampler (llada_forward_block). */
+ * out [n_seq*n_q, d].  block_kv (may be NULL): compact [Q | K | V] rows [n_seq*n_q, 3*d] whose K and V thirds
+ * are used in place of the image's rows block_start .. block_start+n_q-1 of every sequence (the image is only
+ * read).  Used by the block-cached sampler (llada_forward_block). */
 int llada_attn_bidir_queries_bf16(const void* q, int64_t q_stride, int32_t n_q, const void* kv, const uint8_t* key_mask,
-                                  void* out, int32_t n_seq, int32_t seq_len, int32_t n_heads, void* workspace,
-                                  size_t workspace_bytes, void* stream);
+                                  void* out, int32_t n_seq, int32_t seq_len, int32_t n_heads, const void* block_kv,
+                                  int32_t block_start, void* workspace, size_t workspace_bytes, void* stream);
 /* Float32 scratch for the call above (workspace may be NULL): with it, when n_seq * n_heads * ceil(n_q / 128)
  * workgroups would leave most CUs idle, the keys are cut into runs of 64-key tiles, one workgroup each, whose
  * unnormalised partial results a second kernel merges (same softmax, different summation order). */
@@ -193,7 +195,9 @@ size_t llada_attn_workspace_bytes(int32_t n_seq, int32_t n_q, int32_t seq_len, i
  * recomputes only the block_len positions from block_start of every sequence (block_ids
  * [n_seq, block_len]): their keys/values replace the cached ones, their queries attend over the whole
  * cached sequence, and logits_out [n_seq*block_len, vocab] holds their logits.  Keys and values of the
- * other positions stay as they were when the cache was filled.
+ * other positions stay as they were when the cache was filled.  update_cache == 0 leaves the cache untouched
+ * (the block's fresh keys/values are used for this call only: enough when the next call for another block is
+ * preceded by a new llada_forward_fill_cache, as in generate()); the logits are the same either way.
  * ------------------------------------------------------------------------------------------- */
 size_t llada_kv_cache_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len);
 int llada_forward_fill_cache(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
@@ -203,8 +207,8 @@ int llada_forward_fill_cache(const llada_config* cfg, const llada_weights* w, co
 size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len, int32_t block_len);
 int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
                         const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
-                        int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache, void* logits_out,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache, int32_t update_cache,
+                        void* logits_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sampler epilogue: replaces generate.py:81-134 after the forward.

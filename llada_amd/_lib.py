@@ -61,14 +61,14 @@ SIGNATURES = {
     "llada_swiglu_bf16": (C.c_int, [vp, vp, C.c_int64, C.c_int32, vp]),
     "llada_attn_bidir_bf16": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
     "llada_attn_bidir_queries_bf16": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp,
-                                                C.c_size_t, vp]),
+                                                C.c_int32, vp, C.c_size_t, vp]),
     "llada_attn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "llada_kv_cache_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32]),
     "llada_forward_fill_cache": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32, vp,
                                            C.c_int32, vp, vp, C.c_size_t, vp, vp]),
     "llada_forward_block_workspace_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32]),
     "llada_forward_block": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
+                                      C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, C.c_size_t, vp]),
     "llada_num_transfer_tokens": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                             vp, vp]),
     "llada_remask_scores": (C.c_int, [C.POINTER(RemaskArgs), vp]),

@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1))
 attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, const bf16_t* __restrict__ kv_src,
                       int64_t kv_stride, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out, int L, int d,
                       float scale_log2e, int key_splits, int tiles_per_split, float* __restrict__ part_o,
-                      float* __restrict__ part_ml, int64_t n_rows) {
+                      float* __restrict__ part_ml, int64_t n_rows, const bf16_t* __restrict__ blk_kv, int blk_start,
+                      int blk_len) {
     constexpr bool SPLIT = MODE != 0;
     constexpr int NBUF = MODE == 2 ? 1 : 2;
     constexpr int TILE_BYTES = KT * 256;           // one operand, one tile
@@ -64,6 +65,9 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
     // sequence of a [.. | K | V] image (row stride kv_stride, K at column d, V at column 2 d)
     const size_t row_stride = (size_t)kv_stride;
     const bf16_t* base = kv_src + (size_t)b * L * row_stride + (size_t)h * HD;
+    // optional override: keys blk_start .. blk_start + blk_len - 1 of every sequence come from the compact rows
+    // blk_kv [n_seq * blk_len, kv_stride] (the block-cached step's fresh keys/values) instead of the image
+    const bf16_t* blk_base = blk_kv ? blk_kv + (size_t)b * blk_len * row_stride + (size_t)h * HD : nullptr;
 
     // ---- DMA: a tile is 32 pieces of 1 KiB (4 keys x 256 B): pieces 0-15 = K, 16-31 = V ----
     const int p_row = lane >> 4, p_slot = lane & 15;
@@ -72,7 +76,9 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
         const int row = (piece & 15) * 4 + p_row;
         const int chunk = is_v ? ((((p_slot >> 2) ^ (row & 3)) << 2) | (p_slot & 3)) : (p_slot ^ (row & 15));
         const int key = min(kt0 + row, L - 1);
-        const bf16_t* src = base + (size_t)key * row_stride + d + (size_t)is_v * d + chunk * 8;
+        const bool in_blk = blk_base != nullptr && key >= blk_start && key < blk_start + blk_len;
+        const bf16_t* row_ptr = in_blk ? blk_base + (size_t)(key - blk_start) * row_stride : base + (size_t)key * row_stride;
+        const bf16_t* src = row_ptr + d + (size_t)is_v * d + chunk * 8;
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(lds + buf * BUF_BYTES + piece * 1024), 16, 0, 0);
     };
     auto issue_tile = [&](int kt0, int buf) {
@@ -278,16 +284,18 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
 template <int NW>
 void launch_attn(const bf16_t* q, int64_t q_stride, int n_q, const bf16_t* kv, int64_t kv_stride, const uint8_t* key_mask,
                  bf16_t* out, int n_seq, int L, int H, int d, float scale, int key_splits, int tiles_per_split,
-                 float* part_o, float* part_ml, hipStream_t stream) {
+                 float* part_o, float* part_ml, const bf16_t* blk_kv, int blk_start, int blk_len, hipStream_t stream) {
     const int64_t n_rows = (int64_t)n_seq * n_q;
     if (key_splits > 1) {
         dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq * key_splits);
         if (tiles_per_split == 1)
             hipLaunchKernelGGL((attn_bidir_kernel<NW, 2>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
-                               key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows);
+                               key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows, blk_kv,
+                               blk_start, blk_len);
         else
             hipLaunchKernelGGL((attn_bidir_kernel<NW, 1>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
-                               key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows);
+                               key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows, blk_kv,
+                               blk_start, blk_len);
         const int64_t items = n_rows * (d / 4);
         const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
         hipLaunchKernelGGL(attn_combine_kernel, dim3(cgrid), dim3(256), 0, stream, (const float*)part_o,
@@ -296,7 +304,7 @@ void launch_attn(const bf16_t* q, int64_t q_stride, int n_q, const bf16_t* kv, i
     }
     dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq);
     hipLaunchKernelGGL((attn_bidir_kernel<NW, 0>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
-                       key_mask, out, L, d, scale, 1, 0, (float*)nullptr, (float*)nullptr, n_rows);
+                       key_mask, out, L, d, scale, 1, 0, (float*)nullptr, (float*)nullptr, n_rows, blk_kv, blk_start, blk_len);
 }
 
 int g_attn_variant = 0;   // test hook: waves per workgroup (1, 2, 4), 0 = automatic
@@ -324,7 +332,7 @@ extern "C" void llada_attn_force_key_splits(int n) { g_attn_key_splits = n; }
 
 static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16_t* kvp, int64_t kv_stride,
                          const uint8_t* key_mask, bf16_t* op, int n_seq, int seq_len, int n_heads, void* scratch,
-                         size_t scratch_bytes, hipStream_t st) {
+                         size_t scratch_bytes, const bf16_t* blk_kv, int blk_start, int blk_len, hipStream_t st) {
     const int d = n_heads * HD;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     // Waves per workgroup: 4 (128 queries), fewer when a sequence has fewer queries than that.  More waves per
@@ -349,9 +357,9 @@ static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16
         }
     }
     switch (nw) {
-        case 4: launch_attn<4>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, st); break;
-        case 2: launch_attn<2>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, st); break;
-        default: launch_attn<1>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, st); break;
+        case 4: launch_attn<4>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, blk_kv, blk_start, blk_len, st); break;
+        case 2: launch_attn<2>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, blk_kv, blk_start, blk_len, st); break;
+        default: launch_attn<1>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, blk_kv, blk_start, blk_len, st); break;
     }
     LLADA_CHECK_LAUNCH("attn_bidir_kernel");
     return LLADA_OK;
@@ -364,12 +372,14 @@ extern "C" int llada_attn_bidir_bf16(const void* qkv, const uint8_t* key_mask, v
     LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
     const int64_t stride = (int64_t)3 * n_heads * HD;
     return attn_dispatch((const bf16_t*)qkv, stride, seq_len, (const bf16_t*)qkv, stride, key_mask, (bf16_t*)out, n_seq,
-                         seq_len, n_heads, nullptr, 0, (hipStream_t)stream);
+                         seq_len, n_heads, nullptr, 0, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 // Attention of a subset of the positions: n_q query rows per sequence (q [n_seq * n_q, q_stride], head h at column
 // h * 128) over all seq_len keys and values of a [Q | K | V] image kv [n_seq * seq_len, 3 d] (the per-layer cache of
-// the block-cached sampler).  out [n_seq * n_q, d].  With a workspace (llada_attn_workspace_bytes; may be NULL) the
+// the block-cached sampler).  out [n_seq * n_q, d].  block_kv (may be NULL): compact [Q | K | V] rows
+// [n_seq * n_q, 3 d] whose K and V stand in for the image's rows block_start .. block_start + n_q - 1 of every
+// sequence (the image is not touched).  With a workspace (llada_attn_workspace_bytes; may be NULL) the
 // keys are split over several workgroups when the queries alone would leave most CUs idle.
 extern "C" size_t llada_attn_workspace_bytes(int32_t n_seq, int32_t n_q, int32_t seq_len, int32_t n_heads) {
     if (n_seq <= 0 || n_q <= 0 || seq_len <= 0 || n_heads <= 0) return 0;
@@ -380,14 +390,17 @@ extern "C" size_t llada_attn_workspace_bytes(int32_t n_seq, int32_t n_q, int32_t
 
 extern "C" int llada_attn_bidir_queries_bf16(const void* q, int64_t q_stride, int32_t n_q, const void* kv,
                                              const uint8_t* key_mask, void* out, int32_t n_seq, int32_t seq_len,
-                                             int32_t n_heads, void* workspace, size_t workspace_bytes, void* stream) {
+                                             int32_t n_heads, const void* block_kv, int32_t block_start,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
     LLADA_CHECK_ARG(q && kv && out, "attn_queries: null operand");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_heads > 0 && n_q > 0, "attn_queries: bad shape");
     LLADA_CHECK_ARG(q_stride >= (int64_t)n_heads * HD && (q_stride % 8) == 0 && ((uintptr_t)q & 15) == 0,
                     "attn_queries: q_stride must cover the heads and keep rows 16-byte aligned");
     LLADA_CHECK_SUPPORTED(n_seq <= 65535 && n_heads <= 65535, "attn: grid too large");
     LLADA_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "attn_queries: workspace must be 16-byte aligned");
+    LLADA_CHECK_ARG(block_kv == nullptr || (((uintptr_t)block_kv & 15) == 0 && block_start >= 0 && block_start + n_q <= seq_len),
+                    "attn_queries: block_kv must be 16-byte aligned and the block must lie inside the sequence");
     return attn_dispatch((const bf16_t*)q, q_stride, n_q, (const bf16_t*)kv, (int64_t)3 * n_heads * HD, key_mask,
                          (bf16_t*)out, n_seq, seq_len, n_heads, workspace, workspace ? workspace_bytes : 0,
-                         (hipStream_t)stream);
+                         (const bf16_t*)block_kv, block_start, n_q, (hipStream_t)stream);
 }

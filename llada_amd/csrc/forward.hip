@@ -219,7 +219,8 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
 extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
                                    const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                                    int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache,
-                                   void* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
+                                   int32_t update_cache, void* logits_out, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
     LLADA_CHECK_ARG(cfg && w && block_ids && rope_cos && rope_sin && logits_out && workspace && kv_cache,
                     "forward_block: null argument");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && block_len > 0 && block_start >= 0 && block_start + block_len <= seq_len,
@@ -268,7 +269,7 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
                                 0, sk, skb, stream));
             TRY(llada_rope_bf16(qkv, cos_b, sin_b, n_seq, block_len, c.n_heads, stream));
         }
-        {
+        if (update_cache) {
             const int64_t total = Mb * (2 * d / 8);
             const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
             hipLaunchKernelGGL(scatter_kv_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)qkv, image, Mb, block_len,
@@ -276,7 +277,7 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
             LLADA_CHECK_LAUNCH("scatter_kv_kernel");
         }
         TRY(llada_attn_bidir_queries_bf16(qkv, (int64_t)3 * d, block_len, image, key_mask, att, n_seq, seq_len, c.n_heads,
-                                          attn_ws, attn_bytes, stream));
+                                          update_cache ? nullptr : qkv, block_start, attn_ws, attn_bytes, stream));
         TRY(llada_gemm_residual_rmsnorm_bf16(att, w->wo[l], x, h, w->ff_norm[l], c.rms_eps, Mb, d, d, d, tl, sk, skb, stream));
         if (w->packed & 1) {
             TRY(llada_gemm_bf16(h, w->wgu[l], act, Mb, 2 * F, d, d, F, LLADA_EPI_SWIGLU | tf, nullptr, 0, nullptr, nullptr, 0,

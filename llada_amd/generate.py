@@ -118,7 +118,7 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                 x_ = torch.cat([x, un_x], dim=0)
                 if fast:
                     if kv is not None and i > 0:
-                        lg = model.forward_block(x_[:, bs:be], am2, L, bs, kv, out=logits_buf)
+                        lg = model.forward_block(x_[:, bs:be], am2, L, bs, kv, out=logits_buf, update_cache=False)
                     else:
                         lg = model.forward_rows(x_, am2, rows2, out=logits_buf, kv_cache=kv)
                     cond, un = lg[:n_rows], lg[n_rows:]
@@ -131,7 +131,7 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                 un_ptr = un.data_ptr()
             else:
                 if fast and kv is not None and i > 0:
-                    cond = model.forward_block(x[:, bs:be], attention_mask, L, bs, kv, out=logits_buf)
+                    cond = model.forward_block(x[:, bs:be], attention_mask, L, bs, kv, out=logits_buf, update_cache=False)
                     row_pos, nr = rows, n_rows
                 elif fast:
                     cond = model.forward_rows(x, attention_mask, rows, out=logits_buf, kv_cache=kv)   # :92

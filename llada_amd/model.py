@@ -70,10 +70,11 @@ class LLaDAModel:
         need = self.lib.llada_kv_cache_bytes(C.byref(self._c_cfg), n_seq, L)
         return torch.empty(need, dtype=torch.uint8, device=self.device)
 
-    def forward_block(self, block_ids, attention_mask, seq_len, block_start, kv_cache, out=None):
+    def forward_block(self, block_ids, attention_mask, seq_len, block_start, kv_cache, out=None, update_cache=True):
         """Recompute only the positions [block_start, block_start + block_len) of every sequence
         (block_ids [n_seq, block_len]) against ``kv_cache`` (filled by forward_rows(..., kv_cache=)): their
-        keys and values replace the cached ones.  ``attention_mask`` is the full [n_seq, seq_len] mask.
+        keys and values replace the cached ones (``update_cache=False``: they are used for this call only and
+        the cache stays as it is; same logits).  ``attention_mask`` is the full [n_seq, seq_len] mask.
         Returns bf16 logits [n_seq * block_len, V]."""
         assert block_ids.dim() == 2 and block_ids.dtype == torch.long
         ids = block_ids.to(self.device).contiguous()
@@ -93,7 +94,8 @@ class LLaDAModel:
         ws = self._ws_block
         _lib.check(self.lib.llada_forward_block(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
                                                 cos.data_ptr(), sin.data_ptr(), n_seq, seq_len, block_start, bl,
-                                                kv_cache.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                kv_cache.data_ptr(), 1 if update_cache else 0, out.data_ptr(),
+                                                ws.data_ptr(), ws.numel(),
                                                 _lib.stream_ptr()))
         return out
 

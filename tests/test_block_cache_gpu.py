@@ -55,7 +55,7 @@ def test_attention_query_subset_is_exact(lib, n_seq, L, H, q0, n_q, masked):
     q = qkv.reshape(n_seq, L, 3 * d)[:, q0:q0 + n_q].contiguous().reshape(n_seq * n_q, 3 * d)
     sub = torch.full((n_seq * n_q, d), float("nan"), dtype=torch.bfloat16, device="cuda")
     assert lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, n_q, qkv.data_ptr(), None if km is None else km.data_ptr(),
-                                             sub.data_ptr(), n_seq, L, H, None, 0, st) == 0, lib.llada_last_error()
+                                             sub.data_ptr(), n_seq, L, H, None, 0, None, 0, st) == 0, lib.llada_last_error()
     torch.cuda.synchronize()
     want = full.reshape(n_seq, L, d)[:, q0:q0 + n_q].reshape(n_seq * n_q, d)
     assert torch.equal(sub, want)
@@ -64,9 +64,9 @@ def test_attention_query_subset_is_exact(lib, n_seq, L, H, q0, n_q, masked):
 def test_attention_queries_rejects_bad_arguments(lib):
     t = torch.zeros((64, 384), dtype=torch.bfloat16, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 64, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, st) == -1
-    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 384, 0, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, st) == -1
-    assert lib.llada_attn_bidir_queries_bf16(None, 384, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, st) == -1
+    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 64, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, None, 0, st) == -1
+    assert lib.llada_attn_bidir_queries_bf16(t.data_ptr(), 384, 0, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, None, 0, st) == -1
+    assert lib.llada_attn_bidir_queries_bf16(None, 384, 8, t.data_ptr(), None, t.data_ptr(), 1, 64, 1, None, 0, None, 0, st) == -1
 
 
 @pytest.mark.parametrize("splits", [0, 2, 3, 16])
@@ -95,7 +95,7 @@ def test_attention_key_split(lib, n_seq, L, H, q0, n_q, masked, splits):
     kmp = None if km is None else km.data_ptr()
     one = torch.full((n_seq * n_q, d), float("nan"), dtype=torch.bfloat16, device="cuda")
     assert lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, n_q, qkv.data_ptr(), kmp, one.data_ptr(), n_seq, L, H,
-                                             None, 0, st) == 0, lib.llada_last_error()
+                                             None, 0, None, 0, st) == 0, lib.llada_last_error()
     need = lib.llada_attn_workspace_bytes(n_seq, n_q, L, H)
     assert need > 0
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
@@ -103,7 +103,7 @@ def test_attention_key_split(lib, n_seq, L, H, q0, n_q, masked, splits):
     lib.llada_attn_force_key_splits(splits)
     try:
         assert lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, n_q, qkv.data_ptr(), kmp, two.data_ptr(), n_seq, L,
-                                                 H, ws.data_ptr(), ws.numel(), st) == 0, lib.llada_last_error()
+                                                 H, None, 0, ws.data_ptr(), ws.numel(), st) == 0, lib.llada_last_error()
         torch.cuda.synchronize()
     finally:
         lib.llada_attn_force_key_splits(0)
@@ -179,6 +179,30 @@ def test_block_step_matches_oracle(lib, small):
     idn2[:, bs:bs + bl] = blk
     fresh = forward(W, ocfg, idn2, km, emulate_bf16=True)[:, bs:bs + bl].reshape(n_seq * bl, -1)
     assert max_rel(ref, fresh) > 1e-3
+
+
+def test_block_step_without_cache_update_gives_the_same_logits(lib, small):
+    """update_cache=False reads the block's fresh keys/values from the compact rows instead of scattering them
+    into the image first: the attention sees the same bits, so the logits are identical; the cache is untouched."""
+    ocfg, W = small
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(17))
+    n_seq, L, bs, bl = 3, 200, 100, 36           # the block straddles key tiles (64): 100..135
+    ids = torch.from_numpy(g.integers(0, 511, size=(n_seq, L), dtype=np.int64)).cuda()
+    km = np.ones((n_seq, L), dtype=np.int64)
+    km[2, :7] = 0
+    am = torch.from_numpy(km).cuda()
+    kv_a, kv_b = model.kv_cache(n_seq, L), model.kv_cache(n_seq, L)
+    model.forward_rows(ids, am, None, kv_cache=kv_a)
+    kv_b.copy_(kv_a)
+    blk = torch.from_numpy(g.integers(0, 511, size=(n_seq, bl), dtype=np.int64)).cuda()
+    a = model.forward_block(blk, am, L, bs, kv_a, update_cache=True).clone()
+    b = model.forward_block(blk, am, L, bs, kv_b, update_cache=False).clone()
+    assert torch.equal(a, b)
+    assert not torch.equal(kv_a, kv_b)            # only the first call wrote the block's keys/values
+    kv_ref = model.kv_cache(n_seq, L)
+    model.forward_rows(ids, am, None, kv_cache=kv_ref)
+    assert torch.equal(kv_b, kv_ref)
 
 
 def test_block_step_rejects_bad_arguments(lib, small):

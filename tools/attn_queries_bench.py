@@ -12,7 +12,7 @@ for (B, nq, L) in [(1, 32, 384), (8, 32, 384), (2, 128, 1152), (8, 64, 640)]:
     res = []
     for S in (1, 0, 2, 3, 6, 9, 16):
         lib.llada_attn_force_key_splits(S)
-        def call(): lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, nq, kv.data_ptr(), None, out.data_ptr(), B, L, H, ws.data_ptr(), ws.numel(), None)
+        def call(): lib.llada_attn_bidir_queries_bf16(q.data_ptr(), 3 * d, nq, kv.data_ptr(), None, out.data_ptr(), B, L, H, None, 0, ws.data_ptr(), ws.numel(), None)
         ts = []
         for r in range(3):
             for _ in range(3): call()
