@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LLADA_ABI_VERSION 1
+#define LLADA_ABI_VERSION 2
 
 #define LLADA_OK 0
 #define LLADA_ERR_INVALID (-1)      /* bad argument (the Python host raises AssertionError/ValueError) */
@@ -243,12 +243,19 @@ typedef struct llada_remask_args {
     uint32_t row_offset;       /* global index of batch row 0 (data-parallel shards) */
     int64_t* x0;               /* out [B, L]: candidate tokens, generate.py:127 */
     float* confidence;         /* out [B, L]: generate.py:128 (bf16 values except for 'random') */
+    void* workspace;           /* llada_rows_workspace_bytes(n_rows) bytes, 16-byte aligned, or NULL */
+    size_t workspace_bytes;
 } llada_remask_args;
 
 /* Fused generate.py:81,89-90,94-128: one pass over the logits per active row gives the argmax
  * (float64 Gumbel-max when temperature > 0), the softmax statistics and the confidence; rows
  * that are not mask tokens or lie beyond block_end get x0 = x, confidence = -inf, as do all
- * positions no logits row covers. */
+ * positions no logits row covers.
+ * With a workspace, temperature 0 and a rule other than the two entropy rules, every row is cut into
+ * up to 8 pieces streamed by one small workgroup each and merged by a second kernel (a few rows then
+ * still fill the chip; any vocabulary size that is a multiple of 8).  Without one, or for the other
+ * cases, one workgroup holds a whole row on chip (vocabulary <= 131072). */
+size_t llada_rows_workspace_bytes(int32_t n_rows);
 int llada_remask_scores(const llada_remask_args* args, void* stream);
 
 /* generate.py:130-134: per row b, the k = sched[b*sched_stride + step] largest confidences
@@ -273,11 +280,12 @@ int llada_ll_mask(const int64_t* seq, int64_t* noisy, int32_t b, int32_t l, int3
  * above), sum over rows whose noisy token is the mask of CE(logits_row, seq)/p_mask[row's
  * sequence] -> *loss_sum (float64, fixed summation order).  CFG combine fused as above.
  * round_ce_bf16 != 0 rounds each CE to bf16 first, as F.cross_entropy on bf16 logits does.
- * row_loss [n_rows] float32 scratch. */
+ * row_loss [n_rows] float32 scratch.  workspace (llada_rows_workspace_bytes(n_rows) bytes, 16-byte
+ * aligned, or NULL): as for llada_remask_scores, rows are streamed in pieces and merged. */
 int llada_masked_ce(const void* logits, const void* uncond_logits, double cfg_scale, const int32_t* row_pos,
                     int32_t n_rows, int32_t vocab, const int64_t* noisy, const int64_t* seq, int32_t b, int32_t l,
                     int64_t mask_id, const float* p_mask_rows, int32_t round_ce_bf16, float* row_loss,
-                    double* loss_sum, void* stream);
+                    double* loss_sum, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

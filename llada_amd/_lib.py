@@ -39,7 +39,7 @@ class RemaskArgs(C.Structure):
                 ("block_end", C.c_int32), ("mask_id", C.c_int64), ("remasking", C.c_int32), ("flags", C.c_uint32),
                 ("eos_id", C.c_int32), ("eot_id", C.c_int32), ("temperature", C.c_float), ("noise", vp),
                 ("rand_scores", vp), ("seed", C.c_uint64), ("step", C.c_uint32), ("row_offset", C.c_uint32),
-                ("x0", vp), ("confidence", vp)]
+                ("x0", vp), ("confidence", vp), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
 # name -> (restype, argtypes); every symbol include/llada_hip.h declares
@@ -71,15 +71,16 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, C.c_size_t, vp]),
     "llada_num_transfer_tokens": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                             vp, vp]),
+    "llada_rows_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "llada_remask_scores": (C.c_int, [C.POINTER(RemaskArgs), vp]),
     "llada_topk_transfer": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp]),
     "llada_ll_mask": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_uint64, C.c_uint32,
                                 C.c_uint32, vp]),
     "llada_masked_ce": (C.c_int, [vp, vp, C.c_double, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32,
-                                  C.c_int64, vp, C.c_int32, vp, vp, vp]),
+                                  C.c_int64, vp, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
 }
 # test hooks outside the public header
-_EXTRA = {"llada_gemm_force_tile_rows": (None, [C.c_int]), "llada_gemm_use_pipelined": (None, [C.c_int]),
+_EXTRA = {"llada_rows_force_splits": (None, [C.c_int]), "llada_gemm_force_tile_rows": (None, [C.c_int]), "llada_gemm_use_pipelined": (None, [C.c_int]),
           "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_stream_grid": (None, [C.c_int]), "llada_attn_force_variant": (None, [C.c_int]), "llada_attn_force_key_splits": (None, [C.c_int]), "llada_gemm_assume_tiled": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]),
           "llada_gemm_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_longlong]),
           "llada_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)])}
@@ -114,7 +115,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.llada_abi_version() != 1:
+    if lib.llada_abi_version() != 2:
         raise LLaDAHipError("libllada_hip.so ABI version mismatch")
     _lib = lib
     return lib

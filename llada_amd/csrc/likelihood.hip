@@ -10,6 +10,7 @@
 #include "common.h"
 #include "philox.h"
 #include "rowregs.h"
+#include "rowstream.h"
 
 namespace {
 
@@ -79,6 +80,61 @@ __global__ void __launch_bounds__(ROW_THREADS) masked_ce_kernel(const bf16_t* __
     }
 }
 
+// Streamed variant (rowstream.h): block b = piece b % splits of logits row b / splits.
+__global__ void __launch_bounds__(RS_THREADS) ce_stream_kernel(const bf16_t* __restrict__ logits,
+                                                               const bf16_t* __restrict__ uncond, float cfg1,
+                                                               const int32_t* __restrict__ row_pos, int V,
+                                                               const int64_t* __restrict__ noisy, int64_t mask_id,
+                                                               int splits, int cps, RowPart* __restrict__ parts) {
+    __shared__ float red_f[2 * RS_THREADS / 64];
+    __shared__ int red_i[RS_THREADS / 64];
+    const int r = blockIdx.x / splits, sp = blockIdx.x - r * splits;
+    const int pos = row_pos ? row_pos[r] : r;
+    if (noisy[pos] != mask_id) return;
+    const int chunks = V / 8;
+    const int c_begin = sp * cps, c_end = min(chunks, c_begin + cps);
+    const bf16_t* lc = logits + (size_t)r * V;
+    const bf16_t* lu = uncond ? uncond + (size_t)r * V : nullptr;
+    const RowPart p = row_stream_part<true, false>(lc, lu, cfg1, -1, -1, c_begin, c_end, red_f, red_i);
+    if (threadIdx.x == 0) parts[(size_t)r * splits + sp] = p;
+}
+
+// One workgroup: merges the pieces of every row, forms CE / p_mask per row and adds the rows in the
+// same fixed order as sum_rows_kernel.
+__global__ void __launch_bounds__(256) ce_merge_kernel(const bf16_t* __restrict__ logits, const bf16_t* __restrict__ uncond,
+                                                       float cfg1, const int32_t* __restrict__ row_pos, int V,
+                                                       const int64_t* __restrict__ noisy, const int64_t* __restrict__ seq,
+                                                       int l, int64_t mask_id, const float* __restrict__ p_mask_rows,
+                                                       int round_ce, int splits, const RowPart* __restrict__ parts,
+                                                       int n_rows, float* __restrict__ row_loss, double* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+        const int pos = row_pos ? row_pos[r] : r;
+        float loss = 0.f;
+        if (noisy[pos] == mask_id) {
+            const RowPart* p = parts + (size_t)r * splits;
+            float M = p[0].m, S = p[0].s;
+            for (int k = 1; k < splits; ++k) rs_merge(M, S, p[k].m, p[k].s);
+            const int64_t tgt = seq[pos];
+            float lt = bf16_to_f32(logits[(size_t)r * V + tgt]);
+            if (uncond) lt = cfg_combine(lt, bf16_to_f32(uncond[(size_t)r * V + tgt]), cfg1);
+            float logp = (lt - M) - logf(S);
+            if (round_ce) logp = round_bf16(logp);
+            loss = -logp / p_mask_rows[pos / l];
+        }
+        row_loss[r] = loss;
+        acc += (double)loss;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
 __global__ void __launch_bounds__(256) sum_rows_kernel(const float* __restrict__ row_loss, int n,
                                                        double* __restrict__ out) {
     __shared__ double red[256];
@@ -112,13 +168,36 @@ extern "C" int llada_ll_mask(const int64_t* seq, int64_t* noisy, int32_t b, int3
 extern "C" int llada_masked_ce(const void* logits, const void* uncond_logits, double cfg_scale, const int32_t* row_pos,
                                int32_t n_rows, int32_t vocab, const int64_t* noisy, const int64_t* seq, int32_t b,
                                int32_t l, int64_t mask_id, const float* p_mask_rows, int32_t round_ce_bf16,
-                               float* row_loss, double* loss_sum, void* stream) {
+                               float* row_loss, double* loss_sum, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     LLADA_CHECK_ARG(logits && noisy && seq && p_mask_rows && row_loss && loss_sum, "masked_ce: null tensor");
     LLADA_CHECK_ARG(n_rows > 0 && vocab > 0 && b > 0 && l > 0, "masked_ce: bad shape");
     LLADA_CHECK_SUPPORTED(vocab % 8 == 0, "masked_ce: vocab=%d must be a multiple of 8", vocab);
-    LLADA_CHECK_SUPPORTED(vocab <= ROW_MAX_VOCAB, "masked_ce: vocab=%d exceeds %d (one row must fit on chip)", vocab, ROW_MAX_VOCAB);
     LLADA_CHECK_ARG(row_pos != nullptr || n_rows == b * l, "masked_ce: row_pos is required unless n_rows == b*l");
     hipStream_t s = (hipStream_t)stream;
+    if (workspace != nullptr) {
+        LLADA_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "masked_ce: workspace must be 16-byte aligned");
+        const int chunks = vocab / 8;
+        const int splits = rs_pick_splits(n_rows, chunks, llada_rows_forced_splits);
+        if ((size_t)n_rows * splits * sizeof(RowPart) > workspace_bytes) {
+            llada_set_error("masked_ce: workspace of %zu bytes, %zu needed (llada_rows_workspace_bytes)", workspace_bytes,
+                            (size_t)n_rows * splits * sizeof(RowPart));
+            return LLADA_ERR_WORKSPACE;
+        }
+        LLADA_CHECK_SUPPORTED((int64_t)n_rows * splits < 0x7fffffffLL, "masked_ce: grid too large");
+        const int cps = (chunks + splits - 1) / splits;
+        const float cfg1 = (float)(cfg_scale + 1.0);
+        hipLaunchKernelGGL(ce_stream_kernel, dim3(n_rows * splits), dim3(RS_THREADS), 0, s, (const bf16_t*)logits,
+                           (const bf16_t*)uncond_logits, cfg1, row_pos, vocab, noisy, mask_id, splits, cps,
+                           (RowPart*)workspace);
+        LLADA_CHECK_LAUNCH("ce_stream_kernel");
+        hipLaunchKernelGGL(ce_merge_kernel, dim3(1), dim3(256), 0, s, (const bf16_t*)logits, (const bf16_t*)uncond_logits,
+                           cfg1, row_pos, vocab, noisy, seq, l, mask_id, p_mask_rows, round_ce_bf16, splits,
+                           (const RowPart*)workspace, n_rows, row_loss, loss_sum);
+        LLADA_CHECK_LAUNCH("ce_merge_kernel");
+        return LLADA_OK;
+    }
+    LLADA_CHECK_SUPPORTED(vocab <= ROW_MAX_VOCAB, "masked_ce: vocab=%d exceeds %d (one row must fit on chip)", vocab, ROW_MAX_VOCAB);
     static OncePerDevice attr_set;
     if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)masked_ce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

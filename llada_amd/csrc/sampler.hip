@@ -11,6 +11,7 @@
 #include "common.h"
 #include "philox.h"
 #include "rowregs.h"
+#include "rowstream.h"
 
 namespace {
 
@@ -234,6 +235,105 @@ __global__ void __launch_bounds__(ROW_THREADS) remask_rows_kernel(const llada_re
     }
 }
 
+
+// ---- temperature 0, confidence rules and 'random': streamed statistics of row pieces (rowstream.h) ----
+// Block b < n_stream: piece b % splits of logits row b / splits.  The remaining blocks write the
+// defaults (x0 = x, confidence = -inf) of every position; the merge kernel, next on the stream,
+// overwrites the active rows.  ex0 / ex1: vocabulary entries the softmax does not see (or -1).
+template <bool NEED_SUM>
+__global__ void __launch_bounds__(RS_THREADS) remask_stream_kernel(const llada_remask_args a, int splits, int cps,
+                                                                   int ex0, int ex1, RowPart* __restrict__ parts,
+                                                                   int n_stream) {
+    __shared__ float red_f[2 * RS_THREADS / 64];
+    __shared__ int red_i[RS_THREADS / 64];
+    if ((int)blockIdx.x >= n_stream) {
+        const int64_t n = (int64_t)a.B * a.L;
+        const int64_t stride = (int64_t)(gridDim.x - n_stream) * RS_THREADS;
+        for (int64_t i = (int64_t)(blockIdx.x - n_stream) * RS_THREADS + threadIdx.x; i < n; i += stride) {
+            a.x0[i] = a.x[i];
+            a.confidence[i] = -INFINITY;
+        }
+        return;
+    }
+    const int r = blockIdx.x / splits, sp = blockIdx.x - r * splits;
+    const int pos = a.row_pos ? a.row_pos[r] : r;
+    const int col = pos % a.L;
+    if (a.x[pos] != a.mask_id || col >= a.block_end) return;      // uniform exit: the defaults stand
+    const int chunks = a.vocab / 8;
+    const int c_begin = sp * cps, c_end = min(chunks, c_begin + cps);
+    const bf16_t* lc = (const bf16_t*)a.logits + (size_t)r * a.vocab;
+    const bf16_t* lu = a.uncond_logits ? (const bf16_t*)a.uncond_logits + (size_t)r * a.vocab : nullptr;
+    const RowPart p = row_stream_part<NEED_SUM, true>(lc, lu, (float)(a.cfg_scale + 1.0), ex0, ex1, c_begin, c_end,
+                                                      red_f, red_i);
+    if (threadIdx.x == 0) parts[(size_t)r * splits + sp] = p;
+}
+
+// One thread per logits row: merges the pieces in index order, then generate.py:98-128 on the merged
+// statistics.  xa0 / xa1: entries that compete for the arg-max although the softmax does not see them
+// (generate.py:100-101 removes EOS / EoT after x0 is taken), or -1.
+__global__ void __launch_bounds__(256) remask_merge_kernel(const llada_remask_args a, int splits, int ex0, int ex1,
+                                                           int xa0, int xa1, const RowPart* __restrict__ parts) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    const int pos = a.row_pos ? a.row_pos[r] : r;
+    const int b = pos / a.L, col = pos - b * a.L;
+    // the pieces are fetched before the activity test so that their loads travel with that of x[pos]
+    // (an inactive row's stale pieces are read and dropped)
+    const RowPart* p = parts + (size_t)r * splits;
+    RowPart pk[RS_MAX_SPLITS];
+#pragma unroll
+    for (int k = 0; k < RS_MAX_SPLITS; ++k) pk[k] = p[k < splits ? k : 0];
+    if (a.x[pos] != a.mask_id || col >= a.block_end) return;
+    float M = pk[0].m, S = pk[0].s;
+    int x0 = pk[0].idx;
+#pragma unroll
+    for (int k = 1; k < RS_MAX_SPLITS; ++k) {
+        if (k >= splits) break;
+        if (pk[k].m > M) x0 = pk[k].idx;    // strict: the first piece keeps a repeated maximum
+        rs_merge(M, S, pk[k].m, pk[k].s);
+    }
+    const bf16_t* lc = (const bf16_t*)a.logits + (size_t)r * a.vocab;
+    const bf16_t* lu = a.uncond_logits ? (const bf16_t*)a.uncond_logits + (size_t)r * a.vocab : nullptr;
+    const float cfg1 = (float)(a.cfg_scale + 1.0);
+    auto logit = [&](int v) {
+        float l = bf16_to_f32(lc[v]);
+        if (lu) l = cfg_combine(l, bf16_to_f32(lu[v]), cfg1);
+        return l;
+    };
+    float best = M;
+    bool seen = true;            // x0 is an entry the softmax sees: its logit is the maximum M
+    const int xa[2] = {xa0, xa1};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (xa[i] < 0) continue;
+        const float l = logit(xa[i]);
+        if (l > best || (l == best && xa[i] < x0)) {
+            best = l;
+            x0 = xa[i];
+            seen = false;
+        }
+    }
+    float conf;
+    if (a.remasking == LLADA_REMASK_RANDOM) {
+        if (a.rand_scores) {
+            conf = a.rand_scores[pos];
+        } else {
+            uint32_t r0, r1;
+            philox_key(a.seed, LLADA_STREAM_REMASK, r0, r1);
+            const Philox4 ph = philox4x32_10((uint32_t)col, 0u, a.row_offset + (uint32_t)b, a.step, r0, r1);
+            conf = (float)(ph.v[0] >> 8) * (1.0f / 16777216.0f);
+        }
+    } else {
+        const float lx = seen ? M : -INFINITY;
+        const bool f32 = (a.flags & LLADA_FLAG_CONF_FLOAT32) != 0;
+        const float pr = f32 ? expf(lx - M) / S : round_bf16(expf(lx - M) / S);
+        conf = (a.remasking == LLADA_REMASK_LOW_CONFIDENCE) ? pr : (f32 ? 1.0f - pr : round_bf16(1.0f - pr));
+    }
+    a.x0[pos] = (int64_t)x0;
+    a.confidence[pos] = conf;
+}
+
+
 // Order-preserving key of a confidence: NaN ranks highest (torch.topk), -0 == +0.
 __device__ __forceinline__ uint32_t conf_key(float f) {
     if (f != f) return 0xFFFFFFFFu;
@@ -312,7 +412,6 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
     LLADA_CHECK_ARG(a.logits && a.x && a.x0 && a.confidence, "remask_scores: null tensor");
     LLADA_CHECK_ARG(a.n_rows > 0 && a.B > 0 && a.L > 0 && a.vocab > 0, "remask_scores: bad shape");
     LLADA_CHECK_SUPPORTED(a.vocab % 8 == 0, "remask_scores: vocab=%d must be a multiple of 8", a.vocab);
-    LLADA_CHECK_SUPPORTED(a.vocab <= ROW_MAX_VOCAB, "remask_scores: vocab=%d exceeds %d (one row must fit the registers of a workgroup)", a.vocab, ROW_MAX_VOCAB);
     LLADA_CHECK_ARG(a.row_pos != nullptr || a.n_rows == a.B * a.L, "remask_scores: row_pos is required unless n_rows == B*L");
     if (a.remasking < LLADA_REMASK_LOW_CONFIDENCE || a.remasking > LLADA_REMASK_RANDOM) {
         llada_set_error("remask_scores: unknown remasking rule %d", a.remasking);
@@ -324,6 +423,39 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)a.B * a.L;
     const int g = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const bool entropy = a.remasking == LLADA_REMASK_LOW_ENTROPY || a.remasking == LLADA_REMASK_HIGH_ENTROPY;
+    if (a.temperature == 0.0f && !entropy && a.workspace != nullptr) {
+        // streamed row pieces + merge: needs only (max, first arg-max, sum of exponentials) per row
+        LLADA_CHECK_ARG(((uintptr_t)a.workspace & 15) == 0, "remask_scores: workspace must be 16-byte aligned");
+        const int chunks = a.vocab / 8;
+        const int splits = rs_pick_splits(a.n_rows, chunks, llada_rows_forced_splits);
+        if ((size_t)a.n_rows * splits * sizeof(RowPart) > a.workspace_bytes) {
+            llada_set_error("remask_scores: workspace of %zu bytes, %zu needed (llada_rows_workspace_bytes)",
+                            a.workspace_bytes, (size_t)a.n_rows * splits * sizeof(RowPart));
+            return LLADA_ERR_WORKSPACE;
+        }
+        LLADA_CHECK_SUPPORTED((int64_t)a.n_rows * splits + g < 0x7fffffffLL, "remask_scores: grid too large");
+        const int cps = (chunks + splits - 1) / splits;
+        const bool le = (a.flags & LLADA_FLAG_LOGITS_EOS_INF) != 0, ce = (a.flags & LLADA_FLAG_CONF_EOS_EOT_INF) != 0;
+        // generate.py:94-95 removes EOS before the arg-max; :100-101 (temperature 0: one tensor under two
+        // names) removes EOS and EoT from the softmax only
+        const int ex0 = (le || ce) ? a.eos_id : -1, ex1 = ce ? a.eot_id : -1;
+        const int xa0 = (ce && !le) ? a.eos_id : -1, xa1 = ce ? a.eot_id : -1;
+        RowPart* parts = (RowPart*)a.workspace;
+        const int n_stream = a.n_rows * splits;
+        if (a.remasking == LLADA_REMASK_RANDOM)
+            hipLaunchKernelGGL(remask_stream_kernel<false>, dim3(n_stream + g), dim3(RS_THREADS), 0, s, a, splits, cps, ex0,
+                               ex1, parts, n_stream);
+        else
+            hipLaunchKernelGGL(remask_stream_kernel<true>, dim3(n_stream + g), dim3(RS_THREADS), 0, s, a, splits, cps, ex0,
+                               ex1, parts, n_stream);
+        LLADA_CHECK_LAUNCH("remask_stream_kernel");
+        hipLaunchKernelGGL(remask_merge_kernel, dim3((a.n_rows + 255) / 256), dim3(256), 0, s, a, splits, ex0, ex1, xa0, xa1,
+                           (const RowPart*)parts);
+        LLADA_CHECK_LAUNCH("remask_merge_kernel");
+        return LLADA_OK;
+    }
+    LLADA_CHECK_SUPPORTED(a.vocab <= ROW_MAX_VOCAB, "remask_scores: vocab=%d exceeds %d (one row must fit the registers of a workgroup)", a.vocab, ROW_MAX_VOCAB);
     hipLaunchKernelGGL(remask_default_kernel, dim3(g), dim3(256), 0, s, a.x, a.x0, a.confidence, n);
     LLADA_CHECK_LAUNCH("remask_default_kernel");
     static OncePerDevice attr_set;
@@ -343,6 +475,13 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
         hipLaunchKernelGGL(remask_rows_kernel<false>, dim3(a.n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, a);
     LLADA_CHECK_LAUNCH("remask_rows_kernel");
     return LLADA_OK;
+}
+
+int llada_rows_forced_splits = 0;   // test hook: 0 = automatic
+extern "C" void llada_rows_force_splits(int n) { llada_rows_forced_splits = n; }
+
+extern "C" size_t llada_rows_workspace_bytes(int32_t n_rows) {
+    return n_rows > 0 ? (size_t)n_rows * RS_MAX_SPLITS * sizeof(RowPart) : 0;
 }
 
 extern "C" int llada_topk_transfer(int64_t* x, const int64_t* x0, const float* confidence, int32_t B, int32_t L,

@@ -54,6 +54,7 @@ def suffix_greedy_prediction(model, prefix, target, cfg_scale=0., mask_id=126336
     rows = torch.arange(l1, L, device=device, dtype=torch.int32).contiguous()
     rows2 = torch.cat([rows, rows + L]).contiguous() if cfg_scale > 0. else None
     stream = _lib.stream_ptr()
+    ws = torch.empty(lib.llada_rows_workspace_bytes(L), dtype=torch.uint8, device=device)
     for i in range(T):                                                                 # :182
         un_ptr = None
         if cfg_scale > 0.:                                                             # :137-142
@@ -77,7 +78,7 @@ def suffix_greedy_prediction(model, prefix, target, cfg_scale=0., mask_id=126336
         args = _lib.RemaskArgs(cond.data_ptr(), un_ptr, float(cfg_scale), _lib.ptr(row_pos), nr, cond.shape[-1],
                                seq.data_ptr(), 1, L, L, mask_id, _lib.REMASK["low_confidence"],
                                _lib.FLAG_CONF_FLOAT32, EOS_ID, EOT_ID, 0.0, None, None, 0, i, 0,
-                               x0.data_ptr(), conf.data_ptr())
+                               x0.data_ptr(), conf.data_ptr(), ws.data_ptr(), ws.numel())
         _lib.check(lib.llada_remask_scores(C.byref(args), stream))                     # :185-188
         _lib.check(lib.llada_topk_transfer(seq.data_ptr(), x0.data_ptr(), conf.data_ptr(), 1, L,
                                            sched.data_ptr(), sched.shape[1], i, stream))   # :189-191

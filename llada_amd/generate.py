@@ -101,6 +101,9 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
             raise UnboundLocalError("cannot access local variable 'attention_mask_' where it is not associated with a value")
         am2 = torch.cat([attention_mask, attention_mask], dim=0)
     batch_idx = torch.arange(B, device=device, dtype=torch.int32)[:, None] * L
+    # scratch of the streamed row statistics (temperature 0, confidence rules): one allocation per call
+    ws_rows = B * block_length if fast else B * L
+    ws = torch.empty(lib.llada_rows_workspace_bytes(ws_rows), dtype=torch.uint8, device=device)
 
     for num_block in range(num_blocks):                                                   # :74
         bs, be = P + num_block * block_length, P + (num_block + 1) * block_length
@@ -153,7 +156,7 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
             args = _lib.RemaskArgs(cond.data_ptr(), un_ptr, float(cfg_scale), _lib.ptr(row_pos), nr, vocab,
                                    x.data_ptr(), B, L, be, mask_id, _lib.REMASK[remasking], flags, EOS_ID, EOT_ID,
                                    float(temperature), _lib.ptr(noise), _lib.ptr(rand_scores), seed, gstep,
-                                   row_offset, x0.data_ptr(), conf.data_ptr())
+                                   row_offset, x0.data_ptr(), conf.data_ptr(), ws.data_ptr(), ws.numel())
             _lib.check(lib.llada_remask_scores(C.byref(args), stream))                    # :94-128
             _lib.check(lib.llada_topk_transfer(x.data_ptr(), x0.data_ptr(), conf.data_ptr(), B, L,
                                                sched.data_ptr(), steps, i, stream))       # :130-134

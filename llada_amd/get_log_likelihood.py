@@ -112,6 +112,7 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
         n_rows = rows.numel()
         rows2 = torch.cat([rows, rows + b_loc * l]).contiguous() if cfg_scale > 0. else None
         row_loss = torch.empty(n_rows if fast else b_loc * l, dtype=torch.float32, device=device)
+        ws = torch.empty(lib.llada_rows_workspace_bytes(row_loss.numel()), dtype=torch.uint8, device=device)
         stream = _lib.stream_ptr()
         for it in range(n_iter):
             _lib.check(lib.llada_ll_mask(seq_loc.data_ptr(), noisy.data_ptr(), b_loc, l, l1, mask_id,
@@ -139,5 +140,5 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
             _lib.check(lib.llada_masked_ce(cond.data_ptr(), un_ptr, float(cfg_scale), _lib.ptr(row_pos), nr,
                                            cond.shape[-1], noisy.data_ptr(), seq_loc.data_ptr(), b_loc, l, mask_id,
                                            pmask_t[it].data_ptr(), 1 if round_ce_bf16 else 0, row_loss.data_ptr(),
-                                           loss_sums[it:].data_ptr(), stream))                  # :72
+                                           loss_sums[it:].data_ptr(), ws.data_ptr(), ws.numel(), stream))  # :72
     return combine_loss_sums(loss_sums, batch_size, world_size, process_group)

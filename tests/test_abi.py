@@ -24,7 +24,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.llada_abi_version() == 1
+    assert lib.llada_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

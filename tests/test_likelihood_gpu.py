@@ -88,8 +88,10 @@ def test_get_log_likelihood_matches_reference(lib, case):
     assert abs(val - oval) <= 2e-4 * abs(oval), (val, oval)
 
 
-def test_masked_ce_float32_mode(lib):
-    """round_ce_bf16 = 0 keeps float32 cross-entropies; compare with a float64 evaluation."""
+@pytest.mark.parametrize("splits", [None, 1, 3], ids=["whole_row", "stream_1", "stream_3"])
+def test_masked_ce_float32_mode(lib, splits):
+    """round_ce_bf16 = 0 keeps float32 cross-entropies; compare with a float64 evaluation (the whole-row
+    kernel, and the streamed row pieces with one and three pieces per row)."""
     b, l, l1, V = 3, 20, 6, 512
     g = np.random.Generator(np.random.PCG64(3))
     seq = g.integers(0, V, size=(b, l), dtype=np.int64)
@@ -102,9 +104,15 @@ def test_masked_ce_float32_mode(lib):
     out = torch.zeros(1, dtype=torch.float64, device="cuda")
     lgt = dev(lg.reshape(b * l, V)[rows], torch.bfloat16)
     rt, nt, st, pt = dev(rows), dev(noisy), dev(seq), dev(pm)
-    check(lib, lib.llada_masked_ce(lgt.data_ptr(), None, 0.0, rt.data_ptr(), rows.size, V, nt.data_ptr(), st.data_ptr(),
-                                   b, l, MASK_ID, pt.data_ptr(), 0, row_loss.data_ptr(), out.data_ptr(), stream()))
-    torch.cuda.synchronize()
+    ws = None if splits is None else torch.empty(lib.llada_rows_workspace_bytes(rows.size), dtype=torch.uint8, device="cuda")
+    lib.llada_rows_force_splits(splits or 0)
+    try:
+        check(lib, lib.llada_masked_ce(lgt.data_ptr(), None, 0.0, rt.data_ptr(), rows.size, V, nt.data_ptr(), st.data_ptr(),
+                                       b, l, MASK_ID, pt.data_ptr(), 0, row_loss.data_ptr(), out.data_ptr(),
+                                       None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.llada_rows_force_splits(0)
     lp = lg.astype(np.float64)
     lp = lp - np.log(np.exp(lp - lp.max(-1, keepdims=True)).sum(-1, keepdims=True)) - lp.max(-1, keepdims=True)
     ce = -np.take_along_axis(lp, seq[..., None], axis=-1)[..., 0]

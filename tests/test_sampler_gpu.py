@@ -29,6 +29,20 @@ def check(lib, rc):
     assert rc == 0, lib.llada_last_error().decode()
 
 
+ROW_MODE = {"splits": None}
+
+
+@pytest.fixture(autouse=True, params=[None, 1, 3], ids=["whole_row", "stream_1", "stream_3"])
+def row_mode(request, lib):
+    """Every test runs three times: the whole-row kernels (no workspace), and the streamed row pieces
+    (llada_rows_workspace_bytes) with one and with three pieces per row."""
+    ROW_MODE["splits"] = request.param
+    lib.llada_rows_force_splits(request.param or 0)
+    yield
+    lib.llada_rows_force_splits(0)
+    ROW_MODE["splits"] = None
+
+
 def remask(lib, cond, un, cfg, x, block_end, remasking, flags, T, noise=None, rand_scores=None, seed=0, step=0,
            row_offset=0, row_pos=None):
     from llada_amd import _lib
@@ -45,6 +59,9 @@ def remask(lib, cond, un, cfg, x, block_end, remasking, flags, T, noise=None, ra
     args = _lib.RemaskArgs(ct.data_ptr(), _lib.ptr(ut), float(cfg), _lib.ptr(rp), ct.shape[0], V, xt.data_ptr(), B, L,
                            block_end, MASK_ID, _lib.REMASK[remasking], flags, EOS_ID, EOT_ID, float(T), _lib.ptr(nt),
                            _lib.ptr(rt), seed, step, row_offset, x0.data_ptr(), conf.data_ptr())
+    if ROW_MODE["splits"] is not None:
+        ws = torch.empty(lib.llada_rows_workspace_bytes(ct.shape[0]), dtype=torch.uint8, device="cuda")
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib, lib.llada_remask_scores(C.byref(args), stream()))
     torch.cuda.synchronize()
     return x0.cpu().numpy(), conf.cpu().numpy()
@@ -189,6 +206,47 @@ def test_remask_full_vocab(lib):
         ox0, oconf = osamp.confidence_step(x, logits, MASK_ID, L, "low_confidence", T, u, None, True, True)
         assert_x0(x0, ox0, oconf, x)
         compare_conf(conf, oconf, exact=False)
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+@pytest.mark.parametrize("remasking", ["low_confidence", "high_confidence", "random"])
+def test_remask_full_vocab_planted_rows(lib, remasking, flags):
+    """Full-vocabulary rows built to hit the seams of the row kernels: the maximum repeated in far-apart
+    places (the first index must win whichever piece finds it), the maximum on EOS / on EoT (removed
+    before the arg-max, or only from the softmax, depending on the flags), the maximum in the very first
+    and the very last entry, a row that is -inf except for one entry, and an inactive row.  Runs on the
+    whole-row kernel, on 1 and 3 forced pieces, and on the automatic piece count."""
+    V, L = 126464, 9
+    g = np.random.Generator(np.random.PCG64(11))
+    lg = (g.standard_normal((1, L, V), dtype=np.float32) * 2.0).astype(np.float32)
+    top = 30.0
+    lg[0, 0, [70000, 123, 126000]] = top                 # repeated maximum: 123 wins
+    lg[0, 1, [EOS_ID, 90001]] = [top, top - 1.0]         # maximum on EOS
+    lg[0, 2, [EOT_ID, 15]] = [top, top - 0.5]            # maximum on EoT
+    lg[0, 3, 0] = top
+    lg[0, 4, V - 1] = top
+    lg[0, 5, :] = -np.inf
+    lg[0, 5, 77777] = 1.0
+    lg[0, 6, [EOS_ID, EOT_ID]] = top                     # both special tokens tie for the maximum
+    lg[0, 7, [EOT_ID + 8, EOS_ID - 8]] = top             # neighbours of the special tokens
+    from oracle.bf16 import round_bf16
+    lg = round_bf16(lg)
+    x = np.full((1, L), MASK_ID, dtype=np.int64)
+    x[0, 8] = 42                                          # inactive row
+    rs = g.random((1, L)).astype(np.float32)
+    modes = [ROW_MODE["splits"]] + ([0] if ROW_MODE["splits"] == 1 else [])
+    try:
+        for mode in modes:
+            ROW_MODE["splits"] = mode
+            lib.llada_rows_force_splits(mode or 0)
+            x0, conf = remask(lib, lg.reshape(L, V), None, 0.0, x, L, remasking, flags, 0.0, rand_scores=rs)
+            ox0, oconf = osamp.confidence_step(x, lg.copy(), MASK_ID, L, remasking, 0.0, None, rs, bool(flags & 1),
+                                               bool(flags & 2))
+            assert_x0(x0, ox0, oconf, x)
+            compare_conf(conf, oconf, exact=remasking == "random")
+    finally:
+        ROW_MODE["splits"] = modes[0]
+
 
 
 def test_num_transfer_tokens(lib):

@@ -43,30 +43,37 @@ for R in rows_list:
     x0 = torch.empty_like(x)
     conf = torch.empty((1, R), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    for name, rule, temp, cfg in (("low_confidence T=0", "low_confidence", 0.0, 0.0), ("low_entropy T=0", "low_entropy", 0.0, 0.0),
+    ws = torch.empty(lib.llada_rows_workspace_bytes(R), dtype=torch.uint8, device="cuda")
+    for use_ws in (True, False):
+      for name, rule, temp, cfg in (("low_confidence T=0", "low_confidence", 0.0, 0.0), ("low_entropy T=0", "low_entropy", 0.0, 0.0),
                                   ("random T=0", "random", 0.0, 0.0), ("low_confidence T=0 cfg", "low_confidence", 0.0, 1.0),
                                   ("low_confidence T=0.7", "low_confidence", 0.7, 0.0)):
+        if use_ws and (temp != 0.0 or "entropy" in rule):
+            continue                    # those cases always run the whole-row kernel
         def call(i):
             a = _lib.RemaskArgs(ring[i].data_ptr(), un.data_ptr() if cfg else None, cfg, None, R, V, x.data_ptr(), 1, R, R,
                                 MASK, _lib.REMASK[rule], 0, 126081, 126348, temp, None, None, 1, 0, 0, x0.data_ptr(),
-                                conf.data_ptr())
+                                conf.data_ptr(), ws.data_ptr() if use_ws else None, ws.numel() if use_ws else 0)
             _lib.check(lib.llada_remask_scores(C.byref(a), st))
         t = timed(call, n_ring)
         nbytes = R * bytes_row * (2 if cfg else 1)
-        rec = {"kernel": "remask_rows", "case": name, "rows": R, "us": round(t, 1), "GB_s": round(nbytes / t * 1e-3, 1)}
+        rec = {"kernel": "remask_stream" if use_ws else "remask_rows", "case": name, "rows": R, "us": round(t, 1),
+               "GB_s": round(nbytes / t * 1e-3, 1)}
         print(json.dumps(rec), flush=True)
         out.append(rec)
     seq = torch.randint(0, 126000, (1, R), device="cuda")
     pm = torch.full((1,), 0.5, device="cuda")
     rl = torch.empty(R, device="cuda")
     ls = torch.zeros(1, dtype=torch.float64, device="cuda")
-    for cfg in (0.0, 1.0):
+    for use_ws, cfg in ((True, 0.0), (True, 1.0), (False, 0.0), (False, 1.0)):
         def call(i):
             _lib.check(lib.llada_masked_ce(ring[i].data_ptr(), un.data_ptr() if cfg else None, cfg, None, R, V, x.data_ptr(),
-                                           seq.data_ptr(), 1, R, MASK, pm.data_ptr(), 1, rl.data_ptr(), ls.data_ptr(), st))
+                                           seq.data_ptr(), 1, R, MASK, pm.data_ptr(), 1, rl.data_ptr(), ls.data_ptr(),
+                                           ws.data_ptr() if use_ws else None, ws.numel() if use_ws else 0, st))
         t = timed(call, n_ring)
         nbytes = R * bytes_row * (2 if cfg else 1)
-        rec = {"kernel": "masked_ce", "case": f"cfg={cfg}", "rows": R, "us": round(t, 1), "GB_s": round(nbytes / t * 1e-3, 1)}
+        rec = {"kernel": "masked_ce_stream" if use_ws else "masked_ce", "case": f"cfg={cfg}", "rows": R, "us": round(t, 1),
+               "GB_s": round(nbytes / t * 1e-3, 1)}
         print(json.dumps(rec), flush=True)
         out.append(rec)
     del ring
