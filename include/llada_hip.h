@@ -276,6 +276,13 @@ int llada_ll_mask(const int64_t* seq, int64_t* noisy, int32_t b, int32_t l, int3
                   const int32_t* counts, const int32_t* perms, uint64_t seed, uint32_t iteration,
                   uint32_t row_offset, void* stream);
 
+/* The logits rows get_log_likelihood.py:72 actually reads (`logits[mask_index]`): flat indices
+ * r*l + column, ascending, of the mask tokens among the answer columns of noisy [b, l] -> rows_out;
+ * row r's entries start at counts[0] + ... + counts[r-1] (counts as passed to llada_ll_mask, so the
+ * host knows the total without reading anything back).  rows_out [sum(counts)] int32. */
+int llada_ll_masked_rows(const int64_t* noisy, int32_t b, int32_t l, int32_t prompt_len, int64_t mask_id,
+                         const int32_t* counts, int32_t* rows_out, void* stream);
+
 /* get_log_likelihood.py:72-73: for logits rows covering the answer positions (row_pos as
  * above), sum over rows whose noisy token is the mask of CE(logits_row, seq)/p_mask[row's
  * sequence] -> *loss_sum (float64, fixed summation order).  CFG combine fused as above.

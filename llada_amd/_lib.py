@@ -76,6 +76,7 @@ SIGNATURES = {
     "llada_topk_transfer": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp]),
     "llada_ll_mask": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_uint64, C.c_uint32,
                                 C.c_uint32, vp]),
+    "llada_ll_masked_rows": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp]),
     "llada_masked_ce": (C.c_int, [vp, vp, C.c_double, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32,
                                   C.c_int64, vp, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
 }

@@ -48,6 +48,39 @@ __global__ void __launch_bounds__(256) ll_mask_kernel(const int64_t* __restrict_
     }
 }
 
+// Ordered compaction of the masked answer positions: row r writes the flat indices r * l + column of its
+// mask tokens, ascending, starting at sum(counts[0 .. r)) -- the host knows every count (it drew them), so
+// the forward can be asked for exactly these logits rows without reading anything back.
+__global__ void __launch_bounds__(256) ll_masked_rows_kernel(const int64_t* __restrict__ noisy, int l, int prompt_len,
+                                                             int64_t mask_id, const int32_t* __restrict__ counts,
+                                                             int32_t* __restrict__ rows_out) {
+    __shared__ int red[4];
+    __shared__ int wave_tot[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int off = 0;
+    for (int i = tid; i < r; i += 256) off += counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o);
+    if (lane == 0) red[wave] = off;
+    __syncthreads();
+    int base = red[0] + red[1] + red[2] + red[3];
+    const int limit = base + counts[r];          // never write past this row's share
+    const int T = l - prompt_len;
+    for (int j0 = 0; j0 < T; j0 += 256) {
+        const int j = j0 + tid;
+        const bool flag = j < T && noisy[(size_t)r * l + prompt_len + j] == mask_id;
+        const unsigned long long bal = __ballot(flag);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();                         // wave_tot of the previous trip has been read
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int wbase = base;
+        for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+        if (flag && wbase + before < limit) rows_out[wbase + before] = r * l + prompt_len + j;
+        base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    }
+}
+
 // One 1024-thread workgroup per row; the row is read from memory once and kept on chip (rowregs.h).
 __global__ void __launch_bounds__(ROW_THREADS) masked_ce_kernel(const bf16_t* __restrict__ logits,
                                                                 const bf16_t* __restrict__ uncond, float cfg1,
@@ -162,6 +195,17 @@ extern "C" int llada_ll_mask(const int64_t* seq, int64_t* noisy, int32_t b, int3
                        (hipStream_t)stream, seq, noisy, l, prompt_len, mask_id, counts, perms, seed, iteration,
                        row_offset);
     LLADA_CHECK_LAUNCH("ll_mask_kernel");
+    return LLADA_OK;
+}
+
+extern "C" int llada_ll_masked_rows(const int64_t* noisy, int32_t b, int32_t l, int32_t prompt_len, int64_t mask_id,
+                                    const int32_t* counts, int32_t* rows_out, void* stream) {
+    LLADA_CHECK_ARG(noisy && counts && rows_out && b > 0 && l > 0, "ll_masked_rows: bad argument");
+    LLADA_CHECK_ARG(prompt_len >= 0 && prompt_len < l, "ll_masked_rows: prompt_len must leave at least one answer token");
+    LLADA_CHECK_SUPPORTED((int64_t)b * l < 0x7fffffffLL, "ll_masked_rows: b*l too large");
+    hipLaunchKernelGGL(ll_masked_rows_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, noisy, l, prompt_len, mask_id,
+                       counts, rows_out);
+    LLADA_CHECK_LAUNCH("ll_masked_rows_kernel");
     return LLADA_OK;
 }
 

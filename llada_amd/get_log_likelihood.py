@@ -3,8 +3,9 @@ arguments and defaults (:46-47), returns a Python float.
 
 Per Monte-Carlo iteration: forward_process (:7-26) runs as one kernel (stratified mask counts are
 host arithmetic, the random subset comes from the library's Philox stream or from injected
-permutations), the forward computes logits for the answer positions only (prompt tokens are
-never masked, :22), and one kernel fuses the CFG combine, the cross-entropy on the masked
+permutations), the forward computes logits for the masked answer positions only (the reference
+indexes `logits[mask_index]`, :72; the positions are compacted on the device and their number is
+host arithmetic), and one kernel fuses the CFG combine, the cross-entropy on the masked
 positions and the division by p_mask (:72-73).  The host synchronises once, after the last
 iteration (the reference calls .item() every iteration, :75).
 """
@@ -107,11 +108,11 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
         perms_t = None if perms_all is None else torch.from_numpy(np.ascontiguousarray(perms_all[:, r0:r1])).to(device)
         seq_loc = seq[:b_loc]
         noisy = torch.empty_like(seq_loc)
-        rows = (torch.arange(b_loc, device=device, dtype=torch.int32)[:, None] * l +
-                torch.arange(l1, l, device=device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
-        n_rows = rows.numel()
-        rows2 = torch.cat([rows, rows + b_loc * l]).contiguous() if cfg_scale > 0. else None
-        row_loss = torch.empty(n_rows if fast else b_loc * l, dtype=torch.float32, device=device)
+        # answer positions of this rank's rows (protocol-only models return every row anyway)
+        n_ans = b_loc * T
+        masked_per_iter = counts_all[:, r0:r1].astype(np.int64).sum(axis=1)        # known on the host
+        rows_buf = torch.empty(n_ans, dtype=torch.int32, device=device)
+        row_loss = torch.empty(n_ans if fast else b_loc * l, dtype=torch.float32, device=device)
         ws = torch.empty(lib.llada_rows_workspace_bytes(row_loss.numel()), dtype=torch.uint8, device=device)
         stream = _lib.stream_ptr()
         for it in range(n_iter):
@@ -126,7 +127,14 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
             else:
                 batch = noisy
             if fast:
-                lg = model.forward_rows(batch, None, rows2 if cfg_scale > 0. else rows)         # :38
+                # logits only where :72 reads them (`logits[mask_index]`): the masked answer positions,
+                # compacted on the device; their number is the sum of this iteration's counts
+                n_rows = int(masked_per_iter[it])
+                rows = rows_buf[:n_rows]
+                _lib.check(lib.llada_ll_masked_rows(noisy.data_ptr(), b_loc, l, l1, mask_id, counts_t[it].data_ptr(),
+                                                    rows.data_ptr(), stream))
+                rows2 = torch.cat([rows, rows + b_loc * l]).contiguous() if cfg_scale > 0. else rows
+                lg = model.forward_rows(batch, None, rows2)                                     # :38
                 cond = lg[:n_rows]
                 if cfg_scale > 0.:
                     un_ptr = lg[n_rows:].data_ptr()

@@ -140,3 +140,24 @@ def test_ll_mask_philox(lib):
         want[r, l1 + order[: counts[r]]] = MASK_ID
     assert np.array_equal(noisy.cpu().numpy(), want)
     assert ((noisy.cpu().numpy() == MASK_ID).sum(axis=1) == counts).all()
+
+
+def test_ll_masked_rows(lib):
+    """Device compaction of the masked answer positions == numpy's row-major nonzero, for ragged counts
+    (including a row masked completely and answers longer than one 256-thread trip)."""
+    b, l, l1 = 6, 700, 37
+    T = l - l1
+    g = np.random.Generator(np.random.PCG64(8))
+    seq = g.integers(0, 1000, size=(b, l), dtype=np.int64)
+    counts = np.array([1, T, 300, 17, 256, 511], dtype=np.int32)
+    noisy = seq.copy()
+    for r in range(b):
+        noisy[r, l1 + g.permutation(T)[: counts[r]]] = MASK_ID
+    out = torch.full((int(counts.sum()) + 8,), -1, dtype=torch.int32, device="cuda")
+    nt, ct = dev(noisy), dev(counts)
+    check(lib, lib.llada_ll_masked_rows(nt.data_ptr(), b, l, l1, MASK_ID, ct.data_ptr(), out.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    want = np.flatnonzero(noisy.reshape(-1) == MASK_ID).astype(np.int32)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[: want.size], want)
+    assert (got[want.size:] == -1).all()
