@@ -268,11 +268,107 @@ __global__ void __launch_bounds__(RS_THREADS) remask_stream_kernel(const llada_r
     if (threadIdx.x == 0) parts[(size_t)r * splits + sp] = p;
 }
 
+// Temperature > 0: the float64 Gumbel-max of generate.py:16-19,98 over one piece of a row (same ranking
+// as remask_rows_kernel<true>), after the piece's softmax statistics.  The piece is streamed twice (the
+// second time from the cache hierarchy); the float64 logarithms dominate either way.  With 32 or 128
+// active rows (one prompt) the pieces spread that arithmetic over eight times as many CUs.
+struct GumbelPart {
+    double v;
+    int i;
+    int pad;
+};
+
+__global__ void __launch_bounds__(RS_THREADS) remask_stream_gumbel_kernel(const llada_remask_args a, int splits, int cps,
+                                                                          int ex0, int ex1, RowPart* __restrict__ parts,
+                                                                          GumbelPart* __restrict__ gparts, int n_stream) {
+    constexpr int NWV = RS_THREADS / 64;
+    __shared__ float red_f[2 * NWV];
+    __shared__ int red_i[NWV];
+    __shared__ double red_d[NWV];
+    if ((int)blockIdx.x >= n_stream) {
+        const int64_t n = (int64_t)a.B * a.L;
+        const int64_t stride = (int64_t)(gridDim.x - n_stream) * RS_THREADS;
+        for (int64_t i = (int64_t)(blockIdx.x - n_stream) * RS_THREADS + threadIdx.x; i < n; i += stride) {
+            a.x0[i] = a.x[i];
+            a.confidence[i] = -INFINITY;
+        }
+        return;
+    }
+    const int r = blockIdx.x / splits, sp = blockIdx.x - r * splits;
+    const int pos = a.row_pos ? a.row_pos[r] : r;
+    const int b = pos / a.L, col = pos - b * a.L;
+    if (a.x[pos] != a.mask_id || col >= a.block_end) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.vocab, chunks = V / 8;
+    const int c_begin = sp * cps, c_end = min(chunks, c_begin + cps);
+    const bf16_t* lc = (const bf16_t*)a.logits + (size_t)r * V;
+    const bf16_t* lu = a.uncond_logits ? (const bf16_t*)a.uncond_logits + (size_t)r * V : nullptr;
+    const float cfg1 = (float)(a.cfg_scale + 1.0);
+    const bool need_sum = a.remasking != LLADA_REMASK_RANDOM;
+    RowPart p = {-INFINITY, 0.f, 0, 0};
+    if (need_sum) p = row_stream_part<true, false>(lc, lu, cfg1, ex0, ex1, c_begin, c_end, red_f, red_i);
+
+    const bool eos_inf = (a.flags & LLADA_FLAG_LOGITS_EOS_INF) != 0;
+    ArgD bd = {-(double)INFINITY, 0x7fffffff};
+    uint32_t k0, k1;
+    philox_key(a.seed, LLADA_STREAM_GUMBEL, k0, k1);
+    const double temp = (double)a.temperature;
+#pragma unroll 1
+    for (int c = c_begin + tid; c < c_end; c += RS_THREADS) {
+        const u32x4 qv = rs_chunk(lc, lu, cfg1, c, -1, -1);
+        double u[8];
+        if (a.noise) {
+            const double* np = a.noise + (size_t)r * V + (size_t)c * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = np[e];
+        } else {
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) {
+                const Philox4 ph = philox4x32_10((uint32_t)(c * 4 + h2), (uint32_t)col, a.row_offset + (uint32_t)b, a.step,
+                                                 k0, k1);
+                u[2 * h2] = u53(ph.v[0], ph.v[1]);
+                u[2 * h2 + 1] = u53(ph.v[2], ph.v[3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int v = c * 8 + e;
+            float l = (e & 1) ? bf16hi(qv[e >> 1]) : bf16lo(qv[e >> 1]);
+            if (eos_inf && v == a.eos_id) l = -INFINITY;
+            const double sc = (double)l - temp * log(-log(u[e]));    // same arg-max as exp(l) / (-log u) ** T
+            if (sc > bd.v || (sc == bd.v && v < bd.i)) {
+                bd.v = sc;
+                bd.i = v;
+            }
+        }
+    }
+    bd = wave_argmax(bd);
+    __syncthreads();             // red_i may still be read by the statistics above
+    if (lane == 0) {
+        red_d[wave] = bd.v;
+        red_i[wave] = bd.i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bd.v = red_d[0];
+        bd.i = red_i[0];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) bd = arg_better(bd, ArgD{red_d[w], red_i[w]});
+        parts[(size_t)r * splits + sp] = p;
+        GumbelPart gp;
+        gp.v = bd.v;
+        gp.i = bd.i;
+        gp.pad = 0;
+        gparts[(size_t)r * splits + sp] = gp;
+    }
+}
+
 // One thread per logits row: merges the pieces in index order, then generate.py:98-128 on the merged
 // statistics.  xa0 / xa1: entries that compete for the arg-max although the softmax does not see them
 // (generate.py:100-101 removes EOS / EoT after x0 is taken), or -1.
 __global__ void __launch_bounds__(256) remask_merge_kernel(const llada_remask_args a, int splits, int ex0, int ex1,
-                                                           int xa0, int xa1, const RowPart* __restrict__ parts) {
+                                                           int xa0, int xa1, const RowPart* __restrict__ parts,
+                                                           const GumbelPart* __restrict__ gparts) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= a.n_rows) return;
     const int pos = a.row_pos ? a.row_pos[r] : r;
@@ -300,6 +396,32 @@ __global__ void __launch_bounds__(256) remask_merge_kernel(const llada_remask_ar
         if (lu) l = cfg_combine(l, bf16_to_f32(lu[v]), cfg1);
         return l;
     };
+    if (gparts) {
+        // temperature > 0: x0 is the Gumbel arg-max; its logit is read back (it need not be the maximum)
+        ArgD bd = {gparts[(size_t)r * splits].v, gparts[(size_t)r * splits].i};
+        for (int k = 1; k < splits; ++k) bd = arg_better(bd, ArgD{gparts[(size_t)r * splits + k].v, gparts[(size_t)r * splits + k].i});
+        x0 = bd.i;
+        float conf;
+        if (a.remasking == LLADA_REMASK_RANDOM) {
+            if (a.rand_scores) {
+                conf = a.rand_scores[pos];
+            } else {
+                uint32_t r0, r1;
+                philox_key(a.seed, LLADA_STREAM_REMASK, r0, r1);
+                const Philox4 ph = philox4x32_10((uint32_t)col, 0u, a.row_offset + (uint32_t)b, a.step, r0, r1);
+                conf = (float)(ph.v[0] >> 8) * (1.0f / 16777216.0f);
+            }
+        } else {
+            float lx = logit(x0);
+            if (x0 == ex0 || x0 == ex1) lx = -INFINITY;
+            const bool f32 = (a.flags & LLADA_FLAG_CONF_FLOAT32) != 0;
+            const float pr = f32 ? expf(lx - M) / S : round_bf16(expf(lx - M) / S);
+            conf = (a.remasking == LLADA_REMASK_LOW_CONFIDENCE) ? pr : (f32 ? 1.0f - pr : round_bf16(1.0f - pr));
+        }
+        a.x0[pos] = (int64_t)x0;
+        a.confidence[pos] = conf;
+        return;
+    }
     float best = M;
     bool seen = true;            // x0 is an entry the softmax sees: its logit is the maximum M
     const int xa[2] = {xa0, xa1};
@@ -424,25 +546,45 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
     const int64_t n = (int64_t)a.B * a.L;
     const int g = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     const bool entropy = a.remasking == LLADA_REMASK_LOW_ENTROPY || a.remasking == LLADA_REMASK_HIGH_ENTROPY;
-    if (a.temperature == 0.0f && !entropy && a.workspace != nullptr) {
-        // streamed row pieces + merge: needs only (max, first arg-max, sum of exponentials) per row
+    if (!entropy && a.workspace != nullptr) {
+        // streamed row pieces + merge: needs only (max, first arg-max / Gumbel arg-max, sum of exponentials) per row
         LLADA_CHECK_ARG(((uintptr_t)a.workspace & 15) == 0, "remask_scores: workspace must be 16-byte aligned");
+        const bool gumbel = a.temperature != 0.0f;
         const int chunks = a.vocab / 8;
-        const int splits = rs_pick_splits(a.n_rows, chunks, llada_rows_forced_splits);
-        if ((size_t)a.n_rows * splits * sizeof(RowPart) > a.workspace_bytes) {
+        // the float64 Gumbel sweep is arithmetic-bound: always the finest cut that keeps the chip busy
+        int splits = rs_pick_splits(a.n_rows, chunks, llada_rows_forced_splits);
+        if (gumbel && llada_rows_forced_splits <= 0) {
+            splits = 1;
+            while (splits < RS_MAX_SPLITS && (int64_t)a.n_rows * splits < 2048 && chunks / (2 * splits) >= RS_THREADS) splits *= 2;
+        }
+        const size_t per_piece = sizeof(RowPart) + sizeof(GumbelPart);
+        if ((size_t)a.n_rows * splits * per_piece > a.workspace_bytes) {
             llada_set_error("remask_scores: workspace of %zu bytes, %zu needed (llada_rows_workspace_bytes)",
-                            a.workspace_bytes, (size_t)a.n_rows * splits * sizeof(RowPart));
+                            a.workspace_bytes, (size_t)a.n_rows * splits * per_piece);
             return LLADA_ERR_WORKSPACE;
         }
         LLADA_CHECK_SUPPORTED((int64_t)a.n_rows * splits + g < 0x7fffffffLL, "remask_scores: grid too large");
         const int cps = (chunks + splits - 1) / splits;
         const bool le = (a.flags & LLADA_FLAG_LOGITS_EOS_INF) != 0, ce = (a.flags & LLADA_FLAG_CONF_EOS_EOT_INF) != 0;
+        RowPart* parts = (RowPart*)a.workspace;
+        GumbelPart* gparts = (GumbelPart*)(parts + (size_t)a.n_rows * splits);
+        const int n_stream = a.n_rows * splits;
+        if (gumbel) {
+            // generate.py:94-95 removes EOS everywhere; :100-101 removes only EoT from the softmax (the noisy
+            // copy that loses EOS is not used again)
+            const int ex0 = le ? a.eos_id : -1, ex1 = ce ? a.eot_id : -1;
+            hipLaunchKernelGGL(remask_stream_gumbel_kernel, dim3(n_stream + g), dim3(RS_THREADS), 0, s, a, splits, cps, ex0,
+                               ex1, parts, gparts, n_stream);
+            LLADA_CHECK_LAUNCH("remask_stream_gumbel_kernel");
+            hipLaunchKernelGGL(remask_merge_kernel, dim3((a.n_rows + 255) / 256), dim3(256), 0, s, a, splits, ex0, ex1, -1, -1,
+                               (const RowPart*)parts, (const GumbelPart*)gparts);
+            LLADA_CHECK_LAUNCH("remask_merge_kernel");
+            return LLADA_OK;
+        }
         // generate.py:94-95 removes EOS before the arg-max; :100-101 (temperature 0: one tensor under two
         // names) removes EOS and EoT from the softmax only
         const int ex0 = (le || ce) ? a.eos_id : -1, ex1 = ce ? a.eot_id : -1;
         const int xa0 = (ce && !le) ? a.eos_id : -1, xa1 = ce ? a.eot_id : -1;
-        RowPart* parts = (RowPart*)a.workspace;
-        const int n_stream = a.n_rows * splits;
         if (a.remasking == LLADA_REMASK_RANDOM)
             hipLaunchKernelGGL(remask_stream_kernel<false>, dim3(n_stream + g), dim3(RS_THREADS), 0, s, a, splits, cps, ex0,
                                ex1, parts, n_stream);
@@ -451,7 +593,7 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
                                ex1, parts, n_stream);
         LLADA_CHECK_LAUNCH("remask_stream_kernel");
         hipLaunchKernelGGL(remask_merge_kernel, dim3((a.n_rows + 255) / 256), dim3(256), 0, s, a, splits, ex0, ex1, xa0, xa1,
-                           (const RowPart*)parts);
+                           (const RowPart*)parts, (const GumbelPart*)nullptr);
         LLADA_CHECK_LAUNCH("remask_merge_kernel");
         return LLADA_OK;
     }
@@ -481,7 +623,7 @@ int llada_rows_forced_splits = 0;   // test hook: 0 = automatic
 extern "C" void llada_rows_force_splits(int n) { llada_rows_forced_splits = n; }
 
 extern "C" size_t llada_rows_workspace_bytes(int32_t n_rows) {
-    return n_rows > 0 ? (size_t)n_rows * RS_MAX_SPLITS * sizeof(RowPart) : 0;
+    return n_rows > 0 ? (size_t)n_rows * RS_MAX_SPLITS * (sizeof(RowPart) + sizeof(GumbelPart)) : 0;
 }
 
 extern "C" int llada_topk_transfer(int64_t* x, const int64_t* x0, const float* confidence, int32_t B, int32_t L,

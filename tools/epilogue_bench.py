@@ -48,8 +48,8 @@ for R in rows_list:
       for name, rule, temp, cfg in (("low_confidence T=0", "low_confidence", 0.0, 0.0), ("low_entropy T=0", "low_entropy", 0.0, 0.0),
                                   ("random T=0", "random", 0.0, 0.0), ("low_confidence T=0 cfg", "low_confidence", 0.0, 1.0),
                                   ("low_confidence T=0.7", "low_confidence", 0.7, 0.0)):
-        if use_ws and (temp != 0.0 or "entropy" in rule):
-            continue                    # those cases always run the whole-row kernel
+        if use_ws and "entropy" in rule:
+            continue                    # the entropy rules always run the whole-row kernel
         def call(i):
             a = _lib.RemaskArgs(ring[i].data_ptr(), un.data_ptr() if cfg else None, cfg, None, R, V, x.data_ptr(), 1, R, R,
                                 MASK, _lib.REMASK[rule], 0, 126081, 126348, temp, None, None, 1, 0, 0, x0.data_ptr(),
