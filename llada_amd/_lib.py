@@ -11,6 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libllada_hip.so")
 
+ABI_VERSION = 2     # LLADA_ABI_VERSION of include/llada_hip.h this binding was written for
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
 
@@ -116,7 +117,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.llada_abi_version() != 2:
+    if lib.llada_abi_version() != ABI_VERSION:
         raise LLaDAHipError("libllada_hip.so ABI version mismatch")
     _lib = lib
     return lib

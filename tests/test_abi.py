@@ -24,13 +24,17 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.llada_abi_version() == 2
+    assert lib.llada_abi_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "llada_hip.h")).read()
+    assert f"#define LLADA_ABI_VERSION {_lib.ABI_VERSION}\n" in header
 
 
 def test_struct_layouts_match_header():
     # llada_config: 5 x int32 + float; llada_remask_args: field order of the header
     assert C.sizeof(_lib.Config) == 24
     assert [f[0] for f in _lib.RemaskArgs._fields_][:6] == ["logits", "uncond_logits", "cfg_scale", "row_pos", "n_rows", "vocab"]
+    assert [f[0] for f in _lib.RemaskArgs._fields_][-4:] == ["x0", "confidence", "workspace", "workspace_bytes"]
+    assert C.sizeof(_lib.RemaskArgs) == 160 and _lib.RemaskArgs.workspace.offset == 144
     assert C.sizeof(_lib.Weights) == 8 + 9 * 8
 
 
