@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllada_hip.so")
+LIB_PATH = os.environ.get("LLADA_HIP_LIB") or os.path.join(_HERE, "libllada_hip.so")   # override: A/B timing of two builds
 
 ABI_VERSION = 2     # LLADA_ABI_VERSION of include/llada_hip.h this binding was written for
 OK = 0

@@ -46,7 +46,7 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
                       int64_t kv_stride, const uint8_t* __restrict__ key_mask, bf16_t* __restrict__ out, int L, int d,
                       float scale_log2e, int key_splits, int tiles_per_split, float* __restrict__ part_o,
                       float* __restrict__ part_ml, int64_t n_rows, const bf16_t* __restrict__ blk_kv, int blk_start,
-                      int blk_len) {
+                      int blk_len, int n_qblocks, int n_heads) {
     constexpr bool SPLIT = MODE != 0;
     constexpr int NBUF = MODE == 2 ? 1 : 2;
     constexpr int TILE_BYTES = KT * 256;           // one operand, one tile
@@ -57,10 +57,24 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hg = lane >> 5;
-    const int h = blockIdx.y;
-    const int b = SPLIT ? blockIdx.z / key_splits : blockIdx.z;
-    const int ks = SPLIT ? blockIdx.z % key_splits : 0;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    // Work item of this block.  Consecutive blocks are dealt round-robin to the 8 XCDs, each with an L2 of
+    // its own, so the query blocks of one (sequence, head) -- which all stream the same K/V rows -- must be
+    // CONSECUTIVE ITEMS OF ONE XCD, or every one of them pulls its own copy of K/V over the fabric (measured:
+    // without the K/V traffic the kernel is twice as fast).  XCD x works on a contiguous run of items (bijective
+    // for any item count); an item is (query block, head, sequence [x key split]), query block fastest.
+    int qb, h, bz;
+    {
+        const int nt = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, per = nt >> 3, rem = nt & 7;
+        const int item = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (bid >> 3);
+        qb = item % n_qblocks;
+        const int rest = item / n_qblocks;
+        h = rest % n_heads;
+        bz = rest / n_heads;
+    }
+    const int b = SPLIT ? bz / key_splits : bz;
+    const int ks = SPLIT ? bz % key_splits : 0;
+    const int q0 = qb * (NW * 32) + wave * 32;
     // queries: n_q rows per sequence (row stride q_stride, head h at column h * HD); keys and values: L rows per
     // sequence of a [.. | K | V] image (row stride kv_stride, K at column d, V at column 2 d)
     const size_t row_stride = (size_t)kv_stride;
@@ -287,24 +301,27 @@ void launch_attn(const bf16_t* q, int64_t q_stride, int n_q, const bf16_t* kv, i
                  float* part_o, float* part_ml, const bf16_t* blk_kv, int blk_start, int blk_len, hipStream_t stream) {
     const int64_t n_rows = (int64_t)n_seq * n_q;
     if (key_splits > 1) {
-        dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq * key_splits);
+        const int nqb = (n_q + NW * 32 - 1) / (NW * 32);
+        dim3 grid(nqb * H * n_seq * key_splits);
         if (tiles_per_split == 1)
             hipLaunchKernelGGL((attn_bidir_kernel<NW, 2>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
                                key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows, blk_kv,
-                               blk_start, blk_len);
+                               blk_start, blk_len, nqb, H);
         else
             hipLaunchKernelGGL((attn_bidir_kernel<NW, 1>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
                                key_mask, out, L, d, scale, key_splits, tiles_per_split, part_o, part_ml, n_rows, blk_kv,
-                               blk_start, blk_len);
+                               blk_start, blk_len, nqb, H);
         const int64_t items = n_rows * (d / 4);
         const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
         hipLaunchKernelGGL(attn_combine_kernel, dim3(cgrid), dim3(256), 0, stream, (const float*)part_o,
                            (const float*)part_ml, out, n_rows, H, key_splits);
         return;
     }
-    dim3 grid((n_q + NW * 32 - 1) / (NW * 32), H, n_seq);
+    const int nqb = (n_q + NW * 32 - 1) / (NW * 32);
+    dim3 grid(nqb * H * n_seq);
     hipLaunchKernelGGL((attn_bidir_kernel<NW, 0>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
-                       key_mask, out, L, d, scale, 1, 0, (float*)nullptr, (float*)nullptr, n_rows, blk_kv, blk_start, blk_len);
+                       key_mask, out, L, d, scale, 1, 0, (float*)nullptr, (float*)nullptr, n_rows, blk_kv, blk_start, blk_len,
+                       nqb, H);
 }
 
 int g_attn_variant = 0;   // test hook: waves per workgroup (1, 2, 4), 0 = automatic
@@ -356,6 +373,8 @@ static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16
             part_ml = part_o + (size_t)key_splits * n_rows * d;
         }
     }
+    LLADA_CHECK_SUPPORTED((int64_t)((n_q + nw * 32 - 1) / (nw * 32)) * n_heads * n_seq * key_splits < 0x7fffffffLL,
+                          "attn: grid too large");
     switch (nw) {
         case 4: launch_attn<4>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, blk_kv, blk_start, blk_len, st); break;
         case 2: launch_attn<2>(qp, q_stride, n_q, kvp, kv_stride, key_mask, op, n_seq, seq_len, n_heads, d, scale_log2e, key_splits, tiles_per, part_o, part_ml, blk_kv, blk_start, blk_len, st); break;
