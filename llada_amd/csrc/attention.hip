@@ -95,10 +95,33 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
         const bf16_t* src = row_ptr + d + (size_t)is_v * d + chunk * 8;
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(lds + buf * BUF_BYTES + piece * 1024), 16, 0, 0);
     };
+    // Source of every piece this wave moves, for the tile at key 0 (NW >= 4 only): a whole tile that does not
+    // touch the block override is then issued with one 64-bit add per piece; forming each address from
+    // scratch (clamp, override test, 64-bit multiply) costs ~100 vector instructions per tile and wave.
+    [[maybe_unused]] const bf16_t* src0[NW >= 4 ? 32 / NW : 1];
+    if constexpr (NW >= 4) {
+#pragma unroll
+        for (int i = 0; i < 32 / NW; ++i) {
+            const int piece = wave + i * NW;
+            const int is_v = piece >> 4;
+            const int row = (piece & 15) * 4 + p_row;
+            const int chunk = is_v ? ((((p_slot >> 2) ^ (row & 3)) << 2) | (p_slot & 3)) : (p_slot ^ (row & 15));
+            src0[i] = base + (size_t)row * row_stride + d + (size_t)is_v * d + chunk * 8;
+        }
+    }
     auto issue_tile = [&](int kt0, int buf) {
         if constexpr (NW >= 4) {
+            const bool plain = kt0 + KT <= L && (blk_base == nullptr || kt0 + KT <= blk_start || kt0 >= blk_start + blk_len);
+            if (plain) {
+                const size_t adv = (size_t)kt0 * row_stride;       // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 32 / NW; ++i) issue_piece(kt0, buf, wave + i * NW);
+                for (int i = 0; i < 32 / NW; ++i)
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src0[i] + adv),
+                                                     (lds_void_ptr)(lds + buf * BUF_BYTES + (wave + i * NW) * 1024), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32 / NW; ++i) issue_piece(kt0, buf, wave + i * NW);
+            }
         } else {   // short sequences only: a rolled loop keeps the 16-32 source addresses out of registers
 #pragma unroll 1
             for (int piece = wave; piece < 32; piece += NW) issue_piece(kt0, buf, piece);
