@@ -157,12 +157,18 @@ def epilogue_roofline(torch, lib, _lib, device, rows, V, mask_id):
 
     t = timed(rows)
     nbytes = rows * V * 2
+    # HBM-side bytes per launch: separate rocprofv3 --pmc pass (committed record), quoted for the step's 256 rows
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_epilogue_traffic.json")
+    if rows == 256 and os.path.exists(pmc_file):
+        with open(pmc_file) as fh:
+            traffic = json.load(fh).get("traffic_bytes")
     t_big = timed(2048)
     big_bytes = 2048 * V * 2
     return {"bound": "hbm", "kernel": "remask_stream_kernel<true> + remask_merge_kernel (llada_remask_scores as generate() calls "
                                       "it), low_confidence, temperature 0",
             "achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
-            "rows_per_launch": rows, "bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 2), "traffic": None,
+            "rows_per_launch": rows, "bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 2), "traffic": traffic,
             "large_launch": {"rows_per_launch": 2048, "achieved": round(big_bytes / t_big / 1e9, 1),
                              "frac": round(big_bytes / t_big / 8e12, 4), "avg_launch_us": round(t_big * 1e6, 2)}}
 

@@ -8,4 +8,4 @@ for d in sys.argv[1:]:
         k = k[k.find("::") + 2:][:40] if "::" in k else k[:40]
         agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
-        if "gemm" in k or "attn" in k: print(f"{d[-6:]} {k:40s} {c:36s} {statistics.median(v):.4e}  n={len(v)}")
+        if any(t in k for t in ("gemm", "attn", "remask", "ce_")): print(f"{d[-6:]} {k:40s} {c:36s} {statistics.median(v):.4e}  n={len(v)}")
