@@ -2,7 +2,7 @@
 (generate.py:43-45), same return value (a fresh torch.long tensor [B, P+gen_length] on
 ``model.device``), same assertions and NotImplementedError.
 
-The step loop never synchronises the host: the per-row transfer counts live in a device
+The step loop never synchronises the host (one flag is read per block): the per-row transfer counts live in a device
 schedule (get_num_transfer_tokens, generate.py:22-40, runs as a kernel once per block) and the
 top-k transfer reads k from it.  With an ``llada_amd.LLaDAModel`` the forward computes logits
 only for the current block's positions (all other logits are discarded by generate.py:125-128);
@@ -102,13 +102,20 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         am2 = torch.cat([attention_mask, attention_mask], dim=0)
     batch_idx = torch.arange(B, device=device, dtype=torch.int32)[:, None] * L
     # scratch of the streamed row statistics (temperature 0, confidence rules): one allocation per call
-    ws_rows = B * block_length if fast else B * L
+    ws_rows = B * L                                   # B * block_length rows in the usual case
     ws = torch.empty(lib.llada_rows_workspace_bytes(ws_rows), dtype=torch.uint8, device=device)
 
     for num_block in range(num_blocks):                                                   # :74
         bs, be = P + num_block * block_length, P + (num_block + 1) * block_length
         _lib.check(lib.llada_num_transfer_tokens(x.data_ptr(), B, L, bs, be, mask_id, steps, sched.data_ptr(), stream))
-        rows = (batch_idx + torch.arange(bs, be, device=device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        # Logits are needed where a token can be committed: mask tokens left of block_end (:125-128 exclude only
+        # the positions after the block).  Normally those are the block's own positions; a mask token inside the
+        # prompt, or a position of an earlier block for which the model predicted the mask token itself, is a
+        # candidate too in the reference -- one flag read per block decides (the step loop stays free of host reads).
+        row_lo = bs
+        if fast and kv is None and bs > 0 and bool((x[:, :bs] == mask_id).any().item()):   # cache='dual': block rows only
+            row_lo = 0
+        rows = (batch_idx + torch.arange(row_lo, be, device=device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
         n_rows = rows.numel()
         rows2 = torch.cat([rows, rows + B * L]).contiguous() if cfg_scale > 0.0 else None
         logits_buf = None

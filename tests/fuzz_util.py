@@ -1,0 +1,128 @@
+"""Randomised end-to-end check of llada_amd.generate on a small LLaDA-shaped HIP model (GPU only; the oracle
+is the checker): random batch / prompt / generation / block / step shapes, left padding, all five remasking
+rules, temperature 0 and 0.7 (injected noise), classifier-free guidance.  Every step is teacher-forced: the
+oracle's epilogue on the HIP model's own logits of that step's input (requested exactly as generate() requests
+them) must give the same candidates and confidences, the transfers must be the oracle's top-k of them under
+the schedule of generate.py:75-79, and the forward's logits must stay within 2e-2 (max-relative) of the
+oracle model's.  Used by tests/test_fuzz_gpu.py (fixed seeds) and tools/fuzz_generate.py (any seed)."""
+import numpy as np
+import torch
+
+from oracle import sampler as osamp
+from oracle.bf16 import ulp_distance
+from oracle.model import LLaDAConfig as OCfg
+from oracle.model import forward, init_weights
+
+V, MASK_ID = 512, 511      # the mask token is an ordinary word of this small vocabulary
+RULES = ["low_confidence", "high_confidence", "low_entropy", "high_entropy", "random"]
+
+
+def build_model():
+    from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights
+    ocfg = OCfg(d_model=256, n_layers=2, n_heads=2, mlp_hidden=512, vocab_size=V)
+    W = init_weights(ocfg, seed=3, std=0.05, head_scale=4.0)
+    cfg = LLaDAConfig(d_model=256, n_layers=2, n_heads=2, mlp_hidden=512, vocab_size=V)
+    return ocfg, W, LLaDAModel(LLaDAWeights.from_numpy(cfg, W, "cuda"))
+
+
+def run(n_iter, seed, verbose=False, built=None):
+    """Runs n_iter random cases; raises AssertionError (with the case description) on the first mismatch.
+    Returns the worst forward max-relative error seen."""
+    from llada_amd import generate
+    ocfg, W, model = built if built is not None else build_model()
+    g = np.random.Generator(np.random.PCG64(seed))
+    worst_rel = 0.0
+    for it in range(n_iter):
+        B = int(g.integers(1, 6))
+        P = int(g.integers(1, 70))
+        bl = int(g.choice([1, 2, 4, 8, 16, 32, 48]))
+        nb = int(g.integers(1, 4))
+        G = bl * nb
+        spb = int(g.integers(1, bl + 1))             # steps per block
+        steps = spb * nb
+        rule = RULES[int(g.integers(0, 5))]
+        T = float(g.choice([0.0, 0.7]))
+        cfg_scale = float(g.choice([0.0, 0.0, 1.5]))
+        padded = bool(g.integers(0, 2)) or cfg_scale > 0
+        prompt = g.integers(0, MASK_ID, size=(B, P), dtype=np.int64)
+        am = None
+        if padded:
+            am = np.ones((B, P), dtype=np.int64)
+            for b in range(B):
+                am[b, : int(g.integers(0, max(1, P // 2)))] = 0
+        L = P + G
+        noise_log, rand_log, trace = [], [], []
+
+        def noise_fn(shape):
+            u = g.random(shape)
+            noise_log.append(u)
+            return torch.from_numpy(u)
+
+        def rand_fn(shape):
+            r = g.random(shape).astype(np.float32)
+            rand_log.append(r)
+            return torch.from_numpy(r)
+
+        def cb(block, step, x, x0, conf):
+            trace.append((block, x.cpu().numpy().copy(), x0.cpu().numpy().copy(), conf.cpu().numpy().copy()))
+
+        desc = f"it {it}: B={B} P={P} G={G} bl={bl} steps={steps} rule={rule} T={T} cfg={cfg_scale} padded={padded}"
+        out = generate(model, torch.from_numpy(prompt), None if am is None else torch.from_numpy(am), steps=steps, gen_length=G,
+                       block_length=bl, temperature=T, cfg_scale=cfg_scale, remasking=rule, mask_id=MASK_ID,
+                       noise_fn=noise_fn if T else None, rand_fn=rand_fn if rule == "random" else None,
+                       step_callback=cb).cpu().numpy()
+        assert np.array_equal(out[:, :P], prompt), desc
+        # (the mask token is an ordinary word of this small vocabulary: the model may predict it, and such a
+        # position then stays masked, in the reference as here, so "no mask token left" is not asserted)
+        full_mask = None if am is None else np.concatenate([am, np.ones((B, G), np.int64)], 1)
+        x_in = np.full((B, L), MASK_ID, dtype=np.int64)
+        x_in[:, :P] = prompt
+        prompt_index = x_in != MASK_ID
+        for t, (block, x_after, x0, conf) in enumerate(trace):
+            # the step's logits exactly as generate() asks for them: the rows that can matter (the block, or everything
+            # left of its end when an earlier position still holds the mask token), cond | uncond halves under guidance
+            bs_, be_ = P + block * bl, P + (block + 1) * bl
+            if t % spb == 0:
+                row_lo = 0 if (bs_ > 0 and (x_in[:, :bs_] == MASK_ID).any()) else bs_
+            rows = (np.arange(B)[:, None] * L + np.arange(row_lo, be_)[None, :]).reshape(-1).astype(np.int32)
+            fm = None if full_mask is None else torch.from_numpy(full_mask).cuda()
+            lg = np.zeros((B, L, V), dtype=np.float32)
+            if cfg_scale > 0:
+                un = np.where(prompt_index, MASK_ID, x_in)
+                both = np.concatenate([x_in, un])
+                fm2 = torch.from_numpy(np.concatenate([full_mask, full_mask])).cuda()
+                rows2 = torch.from_numpy(np.concatenate([rows, rows + B * L])).cuda()
+                got = model.forward_rows(torch.from_numpy(both).cuda(), fm2, rows2).float().cpu().numpy()
+                lg.reshape(B * L, V)[rows] = osamp.cfg_combine(got[: rows.size], got[rows.size:], cfg_scale)
+            else:
+                got = model.forward_rows(torch.from_numpy(x_in).cuda(), fm, torch.from_numpy(rows).cuda()).float().cpu().numpy()
+                lg.reshape(B * L, V)[rows] = got
+            if t == 0 and cfg_scale == 0:
+                ref = forward(W, ocfg, x_in, full_mask, emulate_bf16=True).reshape(B * L, V)[rows]
+                rel = float(np.abs(got - ref).max() / np.abs(ref).max())
+                worst_rel = max(worst_rel, rel)
+                assert rel <= 2e-2, (desc, rel)
+            u = noise_log[t] if T else None
+            rs = rand_log[t] if rule == "random" else None
+            ox0, oconf = osamp.confidence_step(x_in, lg, MASK_ID, P + (block + 1) * bl, rule, T, u, rs)
+            live = ~np.isneginf(oconf)
+            assert np.array_equal(np.isneginf(conf), np.isneginf(oconf)), (desc, t)
+            assert np.array_equal(x0[live], ox0[live]), (desc, t)
+            fin = live & np.isfinite(oconf)
+            if rule == "random":
+                assert np.array_equal(conf[fin], oconf[fin]), (desc, t)
+            else:
+                # 1 - p inherits one bf16 step of p (2^-8 for p in [0.5, 1)) whatever its own magnitude
+                tol = 2.0 ** -8 if rule == "high_confidence" else 2e-3
+                bad = (ulp_distance(conf[fin], oconf[fin]) > 1) & (np.abs(conf[fin] - oconf[fin]) > tol)
+                assert not bad.any(), (desc, t, conf[fin][bad][:4], oconf[fin][bad][:4])
+            if t % spb == 0:      # generate.py:75-79: the schedule is drawn once per block
+                sched = osamp.get_num_transfer_tokens(x_in[:, P + block * bl: P + (block + 1) * bl] == MASK_ID, spb)
+            expect = x_in.copy()
+            osamp.topk_transfer(expect, x0, conf, sched[:, t % spb])      # lowest index wins a tie, as in the library
+            assert np.array_equal(x_after, expect), (desc, t)
+            x_in = x_after
+        assert np.array_equal(x_in, out), desc
+        if verbose:
+            print("ok", desc, flush=True)
+    return worst_rel

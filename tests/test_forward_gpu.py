@@ -216,3 +216,44 @@ def test_likelihood_end_to_end(lib, tiny):
     a = get_log_likelihood(model, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=16, batch_size=8, mask_id=MASK_ID, seed=5)
     b = get_log_likelihood(model, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=16, batch_size=8, mask_id=MASK_ID, seed=5)
     assert a == b and a < 0
+
+
+def test_generate_mask_tokens_left_of_the_block(lib, tiny):
+    """generate.py:125-128 excludes only the positions AFTER the current block: a mask token inside the prompt
+    (or one the model predicted in an earlier block) is a transfer candidate in every block.  The fast path then
+    asks the forward for those rows as well; every step is checked against the oracle's epilogue on the model's
+    own full logits, and the transfers against the schedule of generate.py:75-79."""
+    from llada_amd import generate
+    from oracle.bf16 import ulp_distance
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(21))
+    B, P, G, bl, steps = 2, 12, 16, 8, 8
+    prompt = g.integers(0, MASK_ID, size=(B, P), dtype=np.int64)
+    prompt[0, 3] = MASK_ID
+    prompt[1, [0, 7]] = MASK_ID
+    trace = []
+    out = generate(model, torch.from_numpy(prompt), steps=steps, gen_length=G, block_length=bl, temperature=0.,
+                   remasking="low_confidence", mask_id=MASK_ID,
+                   step_callback=lambda b, s, x, x0, c: trace.append((b, x.cpu().numpy().copy(), x0.cpu().numpy().copy(),
+                                                                      c.cpu().numpy().copy()))).cpu().numpy()
+    x_in = np.full((B, P + G), MASK_ID, dtype=np.int64)
+    x_in[:, :P] = prompt
+    spb = steps // (G // bl)
+    prompt_candidates = 0
+    for t, (block, x_after, x0, conf) in enumerate(trace):
+        lg = model(torch.from_numpy(x_in).cuda()).logits.float().cpu().numpy()
+        ox0, oconf = osamp.confidence_step(x_in, lg, MASK_ID, P + (block + 1) * bl, "low_confidence")
+        live = ~np.isneginf(oconf)
+        prompt_candidates += int(live[:, :P].sum())
+        assert np.array_equal(np.isneginf(conf), np.isneginf(oconf))
+        assert np.array_equal(x0[live], ox0[live])
+        assert ulp_distance(conf[live], oconf[live]).max(initial=0) <= 1
+        if t % spb == 0:
+            sched = osamp.get_num_transfer_tokens(x_in[:, P + block * bl: P + (block + 1) * bl] == MASK_ID, spb)
+        expect = x_in.copy()
+        osamp.topk_transfer(expect, x0, conf, sched[:, t % spb])
+        assert np.array_equal(x_after, expect)
+        x_in = x_after
+    assert prompt_candidates > 0            # the case really occurred
+    assert np.array_equal(x_in, out)

@@ -1,0 +1,11 @@
+"""Fixed-seed slice of the randomised generate() check (tests/fuzz_util.py)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_generate_random_cases(lib, seed):
+    from tests.fuzz_util import run
+    assert run(25, seed) <= 2e-2

@@ -1,0 +1,13 @@
+"""Randomised end-to-end check of llada_amd.generate against the oracle on a GPU box (tests/fuzz_util.py):
+
+    python tools/fuzz_generate.py [iterations] [seed]
+"""
+import sys
+
+sys.path.insert(0, ".")
+from tests.fuzz_util import run  # noqa: E402
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+worst = run(n_iter, seed, verbose=True)
+print(f"fuzz ok: {n_iter} runs, worst forward max-rel {worst:.2e}")
