@@ -126,3 +126,41 @@ def run(n_iter, seed, verbose=False, built=None):
         if verbose:
             print("ok", desc, flush=True)
     return worst_rel
+
+
+def run_likelihood(n_iter, seed, built=None):
+    """Random get_log_likelihood cases (prompt / answer lengths, batch size, iteration count, guidance, bf16 or
+    float32 cross-entropies, injected k and permutations) on the HIP model against the oracle's estimator fed
+    with the HIP model's own full logits; returns the worst relative difference (contract: 1e-3)."""
+    from llada_amd import get_log_likelihood
+    from oracle import likelihood as oll
+    ocfg, W, model = built if built is not None else build_model()
+    g = np.random.Generator(np.random.PCG64(seed))
+
+    def hip_logits(ids, attention_mask=None):
+        return model(torch.from_numpy(np.ascontiguousarray(ids)).cuda()).logits.float().cpu().numpy()
+
+    worst = 0.0
+    for it in range(n_iter):
+        l1, T = int(g.integers(0, 40)), int(g.integers(1, 70))
+        bs = int(g.choice([1, 2, 3, 4, 8, 16]))
+        n_it = int(g.integers(1, 4))
+        cfg_scale = float(g.choice([0.0, 0.0, 0.5]))
+        rounded = bool(g.integers(0, 2))
+        prompt = g.integers(0, MASK_ID, size=l1, dtype=np.int64)
+        answer = g.integers(0, MASK_ID, size=T, dtype=np.int64)
+        ks = [int(g.integers(1, T + 1)) for _ in range(n_it)]
+        perms = [g.permutation(T) for _ in range(n_it * bs)]
+        desc = f"it {it}: l1={l1} T={T} bs={bs} iters={n_it} cfg={cfg_scale} bf16_ce={rounded}"
+        k1, p1 = list(ks), iter(perms)
+        val = get_log_likelihood(model, torch.from_numpy(prompt), torch.from_numpy(answer), mc_num=n_it * bs, batch_size=bs,
+                                 cfg_scale=cfg_scale, mask_id=MASK_ID, k_fn=lambda t: k1.pop(0), perm_fn=lambda t: next(p1),
+                                 round_ce_bf16=rounded)
+        k2, p2 = list(ks), iter(perms)
+        ref = oll.get_log_likelihood(hip_logits, prompt, answer, mc_num=n_it * bs, batch_size=bs, cfg_scale=cfg_scale,
+                                     mask_id=MASK_ID, k_fn=lambda t: k2.pop(0), perm_fn=lambda t: next(p2),
+                                     round_to_bf16=rounded)
+        rel = abs(val - ref) / abs(ref)
+        worst = max(worst, rel)
+        assert rel <= 1e-3, (desc, val, ref)
+    return worst

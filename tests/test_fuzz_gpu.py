@@ -9,3 +9,9 @@ torch = pytest.importorskip("torch")
 def test_generate_random_cases(lib, seed):
     from tests.fuzz_util import run
     assert run(25, seed) <= 2e-2
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_likelihood_random_cases(lib, seed):
+    from tests.fuzz_util import run_likelihood
+    assert run_likelihood(25, seed) <= 1e-3
