@@ -164,3 +164,63 @@ def run_likelihood(n_iter, seed, built=None):
         worst = max(worst, rel)
         assert rel <= 1e-3, (desc, val, ref)
     return worst
+
+
+def run_attention(n_iter, seed):
+    """Random (sequences, length, heads, key-padding, waves per workgroup, query subset + key splits) calls of
+    the attention entry points against the oracle's float32 attention; returns the worst error relative to the
+    largest reference value (bound used by the kernel tests: 1.5e-2)."""
+    import ctypes as C
+
+    from llada_amd import _lib
+    from oracle import model as omodel
+    from oracle.bf16 import round_bf16
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(seed))
+    st = torch.cuda.current_stream().cuda_stream
+    worst = 0.0
+    for it in range(n_iter):
+        n_seq, L, H = int(g.integers(1, 5)), int(g.integers(1, 700)), int(g.integers(1, 4))
+        d = H * 128
+        waves = int(g.choice([0, 0, 1, 2, 4]))
+        qkv = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
+        qkv[g.integers(0, n_seq * L), d:2 * d] *= 5            # a late jump of the running maximum
+        km = None
+        if g.integers(0, 2):
+            km = (g.random((n_seq, L)) > 0.3).astype(np.uint8)
+            km[:, int(g.integers(0, L))] = 1                      # at least one key per sequence
+        qt = torch.from_numpy(qkv).cuda().to(torch.bfloat16)
+        kmt = None if km is None else torch.from_numpy(km).cuda()
+        x = qkv.reshape(n_seq, L, 3, H, 128)
+        q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+        ref = omodel.attention(q, k, v, km, False).transpose(0, 2, 1, 3).reshape(n_seq, L, d)
+        desc = f"it {it}: n_seq={n_seq} L={L} H={H} waves={waves} masked={km is not None}"
+        lib.llada_attn_force_variant(waves)
+        try:
+            out = torch.full((n_seq * L, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.llada_attn_bidir_bf16(qt.data_ptr(), _lib.ptr(kmt), out.data_ptr(), n_seq, L, H, st))
+            torch.cuda.synchronize()
+            got = out.float().cpu().numpy().reshape(n_seq, L, d)
+            assert np.isfinite(got).all(), desc
+            err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            worst = max(worst, err)
+            assert err <= 1.5e-2, (desc, err)
+            # a query subset [q_lo, q_lo + n_q) of every sequence, with and without the key-split workspace
+            n_q = int(g.integers(1, min(L, 96) + 1))
+            q_lo = int(g.integers(0, L - n_q + 1))
+            qs = qt.reshape(n_seq, L, 3 * d)[:, q_lo:q_lo + n_q].reshape(n_seq * n_q, 3 * d).contiguous()
+            for use_ws in (False, True):
+                nbytes = lib.llada_attn_workspace_bytes(n_seq, n_q, L, H) if use_ws else 0
+                ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda") if use_ws and nbytes else None
+                o2 = torch.full((n_seq * n_q, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+                _lib.check(lib.llada_attn_bidir_queries_bf16(qs.data_ptr(), 3 * d, n_q, qt.data_ptr(), _lib.ptr(kmt),
+                                                             o2.data_ptr(), n_seq, L, H, None, 0, _lib.ptr(ws),
+                                                             0 if ws is None else ws.numel(), st))
+                torch.cuda.synchronize()
+                g2 = o2.float().cpu().numpy().reshape(n_seq, n_q, d)
+                e2 = float(np.abs(g2 - ref[:, q_lo:q_lo + n_q]).max() / np.abs(ref).max())
+                worst = max(worst, e2)
+                assert np.isfinite(g2).all() and e2 <= 1.5e-2, (desc, n_q, q_lo, use_ws, e2)
+        finally:
+            lib.llada_attn_force_variant(0)
+    return worst

@@ -15,3 +15,9 @@ def test_generate_random_cases(lib, seed):
 def test_likelihood_random_cases(lib, seed):
     from tests.fuzz_util import run_likelihood
     assert run_likelihood(25, seed) <= 1e-3
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_attention_random_cases(lib, seed):
+    from tests.fuzz_util import run_attention
+    assert run_attention(20, seed) <= 1.5e-2
