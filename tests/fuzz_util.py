@@ -224,3 +224,49 @@ def run_attention(n_iter, seed):
         finally:
             lib.llada_attn_force_variant(0)
     return worst
+
+
+def run_gemm(n_iter, seed):
+    """Random projection shapes (M any, N % 8 == 0, K % 64 == 0), plain / residual epilogue, forced tile height,
+    split-K workspace, tile-major weights, on small-integer operands: every partial sum is exact in float32, so
+    the result must EQUAL bf16(A W^T [+ R]) whatever the tiling and summation order."""
+    from llada_amd import _lib
+    from llada_amd.weights import tile_major
+    from oracle.bf16 import round_bf16
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(seed))
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        for it in range(n_iter):
+            M = int(g.integers(1, 900))
+            K = 64 * int(g.integers(1, 25))
+            tiled = bool(g.integers(0, 2))
+            N = 256 * int(g.integers(1, 6)) if tiled else 8 * int(g.integers(1, 161))
+            epi = int(g.integers(0, 2))                      # PLAIN / RESIDUAL
+            rows = int(g.choice([0, 128, 192, 256]))
+            use_ws = bool(g.integers(0, 2))
+            A = g.integers(-4, 5, size=(M, K)).astype(np.float32)
+            W = g.integers(-2, 3, size=(N, K)).astype(np.float32)
+            R = g.integers(-64, 65, size=(M, N)).astype(np.float32)
+            ref = round_bf16((A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float32))
+            if epi == 1:
+                ref = round_bf16(ref + R)
+            At = torch.from_numpy(A).cuda().to(torch.bfloat16)
+            Wt = torch.from_numpy(W).cuda().to(torch.bfloat16)
+            if tiled:
+                Wt = tile_major(Wt)
+            Rt = torch.from_numpy(R).cuda().to(torch.bfloat16)
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            ws = torch.empty(lib.llada_gemm_workspace_bytes(M, N, K) + 16, dtype=torch.uint8, device="cuda") if use_ws else None
+            lib.llada_gemm_force_tile_rows(rows)
+            desc = f"it {it}: M={M} N={N} K={K} epi={epi} rows={rows} ws={use_ws} tiled={tiled}"
+            _lib.check(lib.llada_gemm_bf16(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, K, N,
+                                           epi | (_lib.GEMM_W_TILED if tiled else 0), Rt.data_ptr() if epi == 1 else None,
+                                           N if epi == 1 else 0, None, None, 0, _lib.ptr(ws), 0 if ws is None else ws.numel() - 16,
+                                           st))
+            torch.cuda.synchronize()
+            got = out.float().cpu().numpy()
+            assert np.array_equal(got, ref), (desc, int((got != ref).sum()))
+    finally:
+        lib.llada_gemm_force_tile_rows(0)
+    return n_iter

@@ -21,3 +21,9 @@ def test_likelihood_random_cases(lib, seed):
 def test_attention_random_cases(lib, seed):
     from tests.fuzz_util import run_attention
     assert run_attention(20, seed) <= 1.5e-2
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gemm_random_cases(lib, seed):
+    from tests.fuzz_util import run_gemm
+    assert run_gemm(30, seed) == 30
