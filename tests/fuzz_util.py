@@ -270,3 +270,92 @@ def run_gemm(n_iter, seed):
     finally:
         lib.llada_gemm_force_tile_rows(0)
     return n_iter
+
+
+def run_rows(n_iter, seed):
+    """Random calls of llada_remask_scores: vocabulary 8 .. 24000 (multiples of 8), all rules, both EOS controls
+    with the special ids anywhere in the vocabulary, temperature 0 / 0.7 (injected noise), guidance, active-row
+    lists, and every row-kernel form (whole row on chip; streamed pieces: automatic, 1, 3 or 8 per row), against
+    the oracle's confidence_step.  x0 must agree wherever it can be used; confidences within one bf16 step."""
+    import ctypes as C
+
+    from llada_amd import _lib
+    from oracle.bf16 import round_bf16
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(seed))
+    st = torch.cuda.current_stream().cuda_stream
+    saved = osamp.EOS_ID, osamp.EOT_ID
+    try:
+        for it in range(n_iter):
+            V = 8 * int(g.integers(1, 3001))
+            B, L = int(g.integers(1, 4)), int(g.integers(1, 12))
+            rule = RULES[int(g.integers(0, 5))]
+            T = float(g.choice([0.0, 0.0, 0.7]))
+            flags = int(g.integers(0, 4)) if V >= 16 else 0
+            cfg_scale = float(g.choice([0.0, 0.0, 1.5]))
+            mode = [None, 0, 1, 3, 8][int(g.integers(0, 5))]       # None: no workspace
+            eos, eot = (int(v) for v in g.choice(V, size=2, replace=False)) if V >= 16 else (0, 1)
+            osamp.EOS_ID, osamp.EOT_ID = eos, eot
+            mask_id = V - 1
+            x = g.integers(0, max(1, V - 1), size=(B, L), dtype=np.int64)
+            x[g.random((B, L)) < 0.6] = mask_id
+            block_end = int(g.integers(1, L + 1))
+            scale = float(g.choice([1.0, 3.0, 9.0]))
+            cond = round_bf16(g.standard_normal((B, L, V), dtype=np.float32) * np.float32(scale))
+            un = round_bf16(g.standard_normal((B, L, V), dtype=np.float32) * np.float32(scale)) if cfg_scale else None
+            # plant the seams: repeated maximum, maximum on a special token
+            for b in range(B):
+                for col in range(L):
+                    r = g.random()
+                    if r < 0.2:
+                        cond[b, col, g.choice(V, size=min(3, V), replace=False)] = np.float32(4 * scale)
+                    elif r < 0.4:
+                        cond[b, col, eos if r < 0.3 else eot] = np.float32(5 * scale)
+            u = g.random((B, L, V)) if T else None
+            rs = g.random((B, L)).astype(np.float32)
+            logits = osamp.cfg_combine(cond, un, cfg_scale) if cfg_scale else cond.copy()
+            ox0, oconf = osamp.confidence_step(x, logits, mask_id, block_end, rule, T, u, rs, bool(flags & 1), bool(flags & 2))
+            # active-row list: the masked positions left of block_end plus a few others, or every row
+            if g.integers(0, 2):
+                live = np.flatnonzero(((x == mask_id) & (np.arange(L)[None, :] < block_end)).reshape(-1))
+                extra = g.choice(B * L, size=min(B * L, 2), replace=False)
+                rows = np.unique(np.concatenate([live, extra])).astype(np.int32)
+            else:
+                rows = None
+            sel = np.arange(B * L) if rows is None else rows
+            ct = torch.from_numpy(cond.reshape(B * L, V)[sel]).cuda().to(torch.bfloat16).contiguous()
+            ut = None if un is None else torch.from_numpy(un.reshape(B * L, V)[sel]).cuda().to(torch.bfloat16).contiguous()
+            nt = None if u is None else torch.from_numpy(u.reshape(B * L, V)[sel]).cuda().contiguous()
+            rt = torch.from_numpy(rs).cuda()
+            xt = torch.from_numpy(x).cuda()
+            rp = None if rows is None else torch.from_numpy(rows).cuda()
+            x0 = torch.full((B, L), -7, dtype=torch.long, device="cuda")
+            conf = torch.full((B, L), 123.0, dtype=torch.float32, device="cuda")
+            args = _lib.RemaskArgs(ct.data_ptr(), _lib.ptr(ut), cfg_scale, _lib.ptr(rp), ct.shape[0], V, xt.data_ptr(), B, L,
+                                   block_end, mask_id, _lib.REMASK[rule], flags, eos, eot, T, _lib.ptr(nt), rt.data_ptr(), 5, 2, 1,
+                                   x0.data_ptr(), conf.data_ptr())
+            if mode is not None:
+                ws = torch.empty(lib.llada_rows_workspace_bytes(ct.shape[0]), dtype=torch.uint8, device="cuda")
+                args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+                lib.llada_rows_force_splits(mode)
+            desc = (f"it {it}: V={V} B={B} L={L} rule={rule} T={T} flags={flags} cfg={cfg_scale} mode={mode} eos={eos} eot={eot} "
+                    f"block_end={block_end} rows={'all' if rows is None else rows.size}")
+            _lib.check(lib.llada_remask_scores(C.byref(args), st))
+            torch.cuda.synchronize()
+            gx0, gconf = x0.cpu().numpy(), conf.cpu().numpy()
+            livem = ~np.isneginf(oconf)
+            assert np.array_equal(np.isneginf(gconf), np.isneginf(oconf)), desc
+            assert np.array_equal(np.isnan(gconf), np.isnan(oconf)), desc
+            assert np.array_equal(gx0[livem], ox0[livem]), desc
+            assert np.array_equal(gx0[~livem], x[~livem]), desc
+            fin = np.isfinite(oconf)
+            if rule == "random":
+                assert np.array_equal(gconf[fin], oconf[fin]), desc
+            else:
+                tol = 2.0 ** -8 if rule == "high_confidence" else (4e-7 if "entropy" in rule else 0.0)
+                bad = (ulp_distance(gconf[fin], oconf[fin]) > 1) & (np.abs(gconf[fin] - oconf[fin]) > tol)
+                assert not bad.any(), (desc, gconf[fin][bad][:4], oconf[fin][bad][:4])
+    finally:
+        osamp.EOS_ID, osamp.EOT_ID = saved
+        lib.llada_rows_force_splits(0)
+    return n_iter

@@ -27,3 +27,9 @@ def test_attention_random_cases(lib, seed):
 def test_gemm_random_cases(lib, seed):
     from tests.fuzz_util import run_gemm
     assert run_gemm(30, seed) == 30
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_remask_random_cases(lib, seed):
+    from tests.fuzz_util import run_rows
+    assert run_rows(40, seed) == 40
