@@ -173,6 +173,53 @@ def epilogue_roofline(torch, lib, _lib, device, rows, V, mask_id):
                              "frac": round(big_bytes / t_big / 8e12, 4), "avg_launch_us": round(t_big * 1e6, 2)}}
 
 
+def likelihood_bench(args, torch, dist, model, cfg, world, rank, device, backend):
+    """BASELINE configuration 4: get_log_likelihood(mc_num=128, batch_size=32) on synthetic ids, the 32 rows of
+    every Monte Carlo iteration dealt over the ranks, one all-reduce of the per-iteration loss sums per call."""
+    from llada_amd import get_log_likelihood
+    gen = torch.Generator().manual_seed(4321)
+    prompt = torch.randint(0, 126000, (256,), generator=gen, dtype=torch.long)
+    answer = torch.randint(0, 126000, (128,), generator=gen, dtype=torch.long)
+    mc_num, batch_size = 128, 32
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def call():
+        return get_log_likelihood(model, prompt, answer, mc_num=mc_num, batch_size=batch_size, seed=7, rank=rank,
+                                  world_size=world)
+    W_, K_ = max(args.warmup, 1), args.steps
+    for _ in range(min(W_, 2)):
+        val = call()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(K_):
+        val = call()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        l = 384
+        flops = (mc_num * l) * 2.0 * (cfg.n_layers * (4 * cfg.d_model ** 2 + 3 * cfg.d_model * cfg.mlp_hidden)) \
+            + mc_num * 4.0 * l * l * cfg.d_model * cfg.n_layers
+        rec = {"metric": "get_log_likelihood calls/s, LLaDA-8B mc_num=128 batch_size=32 (prompt 256 + answer 128 tokens)",
+               "value": round(K_ / elapsed, 4), "unit": "calls/s", "n_gpus": world, "steps": K_, "warmup": min(W_, 2),
+               "ms_per_step": round(1e3 * elapsed / K_, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "get_log_likelihood(): mc_num=128, batch_size=32 (4 iterations), 384 tokens per row, rows of "
+                                      "every iteration split over the ranks, all-reduce of the loss sums",
+                          "layers": cfg.n_layers, "parallelism": f"dp{world}"},
+               "log_likelihood": round(val, 4),
+               "mfma_util_layers": round(flops / (elapsed / K_) / 1e12 / PEAK_BF16_TFLOPS / world, 4)}
+        print(json.dumps(rec), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +232,9 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers makes the result INVALID")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency leg")
+    ap.add_argument("--workload", choices=["generate", "likelihood"], default="generate",
+                    help="likelihood: get_log_likelihood(mc_num=128, batch_size=32), prompt 256 + answer 128 tokens, the MC rows of "
+                         "every iteration split over the ranks and the loss sums all-reduced (strong scaling; a step = one call)")
     args = ap.parse_args()
 
     import torch
@@ -211,6 +261,13 @@ def main():
     cfg = LLaDAConfig(n_layers=args.layers)
     model = LLaDAModel(LLaDAWeights.random(cfg, device, seed=0))
     lib = _lib.load()
+
+    if args.workload == "likelihood":
+        likelihood_bench(args, torch, dist, model, cfg, world, rank, device, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B, P, G, bl = args.batch, args.prompt, args.gen, args.block
     L = P + G

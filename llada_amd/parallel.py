@@ -49,9 +49,13 @@ def generate_data_parallel(generate_fn, model, prompt, attention_mask=None, *arg
     buf = torch.zeros((max_rows, L), dtype=dtype, device=device)
     if local is not None:
         buf[: hi - lo] = local
+    on_host = buf.is_cuda and dist.get_backend(process_group) == "gloo"   # a CPU-only process group (rehearsals)
+    if on_host:
+        buf = buf.cpu()
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf, group=process_group)
-    return torch.cat([gathered[r][: bounds[r + 1] - bounds[r]] for r in range(world)], dim=0)
+    out = torch.cat([gathered[r][: bounds[r + 1] - bounds[r]] for r in range(world)], dim=0)
+    return out.to(device) if on_host else out
 
 
 def combine_loss_sums(loss_sums, batch_size, world_size=1, process_group=None):
@@ -59,6 +63,8 @@ def combine_loss_sums(loss_sums, batch_size, world_size=1, process_group=None):
     sum of CE/p_mask per iteration; one all-reduce(sum), then loss = sum / batch_size per
     iteration and the result is minus their mean.  The only host synchronisation of the call."""
     if world_size > 1:
+        if loss_sums.is_cuda and dist.get_backend(process_group) == "gloo":
+            loss_sums = loss_sums.cpu()        # a CPU-only process group (rehearsals): reduce on the host
         dist.all_reduce(loss_sums, op=dist.ReduceOp.SUM, group=process_group)
     loss_ = (loss_sums / batch_size).cpu().tolist()
     return - sum(loss_) / len(loss_)
