@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from .generate import EOS_ID, EOT_ID, generate
-from .get_log_likelihood import get_log_likelihood
+from .get_log_likelihood import get_log_likelihood, get_log_likelihood_many
 from .model import LLaDAModel
 
 try:                                                    # eval_llada.py:12-15
@@ -100,7 +100,7 @@ class LLaDAEvalHarness(_Base):
     def __init__(self, model_path='', mask_id=126336, max_length=4096, batch_size=32, mc_num=128,
                  is_check_greedy=True, cfg=0., steps=1024, gen_length=1024, block_length=1024,
                  remasking='low_confidence', device="cuda", *, model=None, tokenizer=None, process_group=None,
-                 seed=1234, **kwargs):
+                 seed=1234, rows_per_forward=32, **kwargs):
         """Keywords as eval_llada.py:33-48.  ``model=`` / ``tokenizer=`` take ready objects; otherwise
         both are loaded from the local directory ``model_path``."""
         if _Base is not object:
@@ -132,6 +132,7 @@ class LLaDAEvalHarness(_Base):
         self.block_length = block_length
         self.remasking = remasking
         self.seed = seed
+        self.rows_per_forward = int(rows_per_forward)   # Monte-Carlo rows of several requests per forward
         self._n_ll = 0
 
     @property
@@ -171,11 +172,19 @@ class LLaDAEvalHarness(_Base):
         """eval_llada.py:210-241: [(log-likelihood, 1.0 if the target is the greedy fill else 0.0)]."""
         pairs = [self._encode_pair(req.args[0], req.args[1]) for req in requests]
         assert max((len(p) + len(t) for p, t in pairs), default=0) <= 4096            # :227
+        pairs = [(torch.tensor(p, dtype=torch.long), torch.tensor(t, dtype=torch.long)) for p, t in pairs]
+        if isinstance(self.model, LLaDAModel) and len(pairs) > 1:
+            # the Monte-Carlo rows of different requests share forwards (same masks per request as the
+            # one-by-one calls: request j of this call draws from the key its own call would have used)
+            seeds = [self.seed + self._n_ll + j + 1 for j in range(len(pairs))]
+            self._n_ll += len(pairs)
+            lls = get_log_likelihood_many(self.model, pairs, mc_num=self.mc_num, batch_size=self.batch_size,
+                                          cfg_scale=self.cfg, mask_id=self.mask_id, seeds=seeds,
+                                          max_rows=max(self.batch_size, self.rows_per_forward))
+        else:
+            lls = [self.get_loglikelihood(prefix, target) for prefix, target in pairs]
         out = []
-        for prefix, target in pairs:
-            prefix = torch.tensor(prefix, dtype=torch.long)
-            target = torch.tensor(target, dtype=torch.long)
-            ll = self.get_loglikelihood(prefix, target)
+        for (prefix, target), ll in zip(pairs, lls):
             is_target_greedy_dec = self.suffix_greedy_prediction(prefix, target)
             out.append((ll, 1.0 if is_target_greedy_dec else 0.0))
         return out

@@ -150,3 +150,89 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
                                            pmask_t[it].data_ptr(), 1 if round_ce_bf16 else 0, row_loss.data_ptr(),
                                            loss_sums[it:].data_ptr(), ws.data_ptr(), ws.numel(), stream))  # :72
     return combine_loss_sums(loss_sums, batch_size, world_size, process_group)
+
+
+@torch.no_grad()
+def get_log_likelihood_many(model, pairs, mc_num=128, batch_size=16, cfg_scale=0., mask_id=126336, *, seeds=None,
+                            max_rows=64, round_ce_bf16=True):
+    '''The estimator of get_log_likelihood (get_log_likelihood.py:46-77) for several (prompt, answer) pairs at
+    once: the Monte-Carlo rows of different requests share forwards (the reference's harness loops over requests,
+    eval_llada.py:231-238, so a request with mc_num = batch_size = 1 runs the model on a single short row).
+    Rows are right-padded to the longest of their forward and the padding is masked as attention keys, which
+    leaves every real position's arithmetic unchanged; ``seeds[i]`` keys request i's masks exactly as
+    ``get_log_likelihood(..., seed=seeds[i])`` does.  Padding and masking change nothing (a right-padded, masked
+    row gives bit-identical logits to the bare row); what differs from the one-by-one calls is the number of rows
+    per forward, hence the GEMM tiling and the last bits of every bf16 rounding -- the same run-to-run noise the
+    reference has between batch sizes.  ``max_rows``: rows per forward.  llada_amd.LLaDAModel only.
+    Returns a list of floats.'''
+    assert isinstance(model, LLaDAModel), "get_log_likelihood_many needs an llada_amd.LLaDAModel"
+    lib = _lib.load()
+    device = torch.device(model.device)
+    n_iter = mc_num // batch_size                                                               # :66
+    if n_iter == 0:
+        raise ZeroDivisionError("division by zero")
+    if seeds is None:
+        seeds = list(range(len(pairs)))
+    assert len(seeds) == len(pairs)
+    stream = _lib.stream_ptr()
+    # one group = the batch_size rows of one iteration of one request
+    groups = []
+    for i, (prompt, answer) in enumerate(pairs):
+        seq = torch.cat([prompt.to(device), answer.to(device)]).to(torch.long)                  # :61
+        l1, l = len(prompt), seq.numel()
+        T = l - l1
+        assert T >= 1
+        for it in range(n_iter):
+            counts = stratified_counts(rng.ll_k(seeds[i], it, T), batch_size, T)                # :10-14
+            groups.append((i, it, seq, l1, l, counts))
+    sums = np.zeros((len(pairs), n_iter), dtype=np.float64)
+    g0 = 0
+    while g0 < len(groups):
+        g1 = g0 + 1
+        while g1 < len(groups) and (g1 + 1 - g0) * batch_size <= max(max_rows, batch_size):
+            g1 += 1
+        chunk = groups[g0:g1]
+        R, Lmax = len(chunk) * batch_size, max(g[4] for g in chunk)
+        noisy = torch.zeros((R, Lmax), dtype=torch.long, device=device)
+        seqs = torch.zeros((R, Lmax), dtype=torch.long, device=device)
+        keym = torch.zeros((R, Lmax), dtype=torch.long, device=device)
+        answer_region = torch.zeros((R, Lmax), dtype=torch.bool, device=device)
+        prompt_region = torch.zeros((R, Lmax), dtype=torch.bool, device=device)
+        p_mask = np.zeros(R, dtype=np.float32)
+        for j, (i, it, seq, l1, l, counts) in enumerate(chunk):
+            r0 = j * batch_size
+            rep = seq[None, :].repeat(batch_size, 1).contiguous()                               # :62
+            out = torch.empty_like(rep)
+            counts_t = torch.from_numpy(counts.astype(np.int32)).to(device)
+            _lib.check(lib.llada_ll_mask(rep.data_ptr(), out.data_ptr(), batch_size, l, l1, mask_id, counts_t.data_ptr(),
+                                         None, seeds[i], it, 0, stream))                        # :67
+            noisy[r0:r0 + batch_size, :l] = out
+            seqs[r0:r0 + batch_size, :l] = rep
+            keym[r0:r0 + batch_size, :l] = 1
+            answer_region[r0:r0 + batch_size, l1:l] = True
+            prompt_region[r0:r0 + batch_size, :l1] = True
+            p_mask[r0:r0 + batch_size] = counts.astype(np.float32) / np.float32(l - l1)         # :26
+        rows = torch.nonzero(((noisy == mask_id) & answer_region).reshape(-1)).reshape(-1).to(torch.int32).contiguous()
+        n_rows = rows.numel()
+        un_ptr = None
+        if cfg_scale > 0.:                                                                      # :30-35
+            batch = torch.cat([noisy, torch.where(prompt_region, mask_id, noisy)])
+            km = torch.cat([keym, keym])
+            lg = model.forward_rows(batch, km, torch.cat([rows, rows + R * Lmax]).contiguous())
+            un_ptr = lg[n_rows:].data_ptr()
+        else:
+            lg = model.forward_rows(noisy, keym, rows)                                          # :38
+        row_loss = torch.empty(n_rows, dtype=torch.float32, device=device)
+        total = torch.zeros(1, dtype=torch.float64, device=device)
+        ws = torch.empty(lib.llada_rows_workspace_bytes(n_rows), dtype=torch.uint8, device=device)
+        pm_t = torch.from_numpy(p_mask).to(device)
+        _lib.check(lib.llada_masked_ce(lg.data_ptr(), un_ptr, float(cfg_scale), rows.data_ptr(), n_rows, lg.shape[-1],
+                                       noisy.data_ptr(), seqs.data_ptr(), R, Lmax, mask_id, pm_t.data_ptr(),
+                                       1 if round_ce_bf16 else 0, row_loss.data_ptr(), total.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), stream))                                     # :72
+        losses = row_loss.cpu().numpy().astype(np.float64)
+        group_of_row = (rows.cpu().numpy() // Lmax) // batch_size
+        for j, (i, it, *_rest) in enumerate(chunk):
+            sums[i, it] = losses[group_of_row == j].sum()                                       # row order, float64
+        g0 = g1
+    return [- sum((sums[i] / batch_size).tolist()) / n_iter for i in range(len(pairs))]         # :73-77

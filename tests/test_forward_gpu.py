@@ -257,3 +257,24 @@ def test_generate_mask_tokens_left_of_the_block(lib, tiny):
         x_in = x_after
     assert prompt_candidates > 0            # the case really occurred
     assert np.array_equal(x_in, out)
+
+
+@pytest.mark.parametrize("mc_num,batch_size,cfg_scale", [(1, 1, 0.0), (4, 2, 0.0), (6, 3, 0.5), (8, 8, 0.0)])
+def test_likelihood_many_matches_one_by_one(lib, tiny, mc_num, batch_size, cfg_scale):
+    """Requests of different lengths batched into shared, right-padded forwards give the values of the
+    one-by-one calls with the same seeds (same masks; only the GEMM tiling of the forward differs)."""
+    from llada_amd import get_log_likelihood, get_log_likelihood_many
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(31))
+    pairs = []
+    for l1, T in ((9, 15), (0, 4), (30, 1), (17, 40), (5, 5), (12, 33), (3, 70)):
+        pairs.append((torch.from_numpy(g.integers(0, MASK_ID, size=l1, dtype=np.int64)),
+                      torch.from_numpy(g.integers(0, MASK_ID, size=T, dtype=np.int64))))
+    seeds = [100 + 7 * i for i in range(len(pairs))]
+    many = get_log_likelihood_many(model, pairs, mc_num=mc_num, batch_size=batch_size, cfg_scale=cfg_scale, mask_id=MASK_ID,
+                                   seeds=seeds, max_rows=10)
+    for (p, a), s, v in zip(pairs, seeds, many):
+        one = get_log_likelihood(model, p, a, mc_num=mc_num, batch_size=batch_size, cfg_scale=cfg_scale, mask_id=MASK_ID,
+                                 seed=s)
+        assert abs(v - one) <= 1e-3 * abs(one), (len(p), len(a), v, one)
