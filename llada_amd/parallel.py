@@ -4,7 +4,8 @@
   * generate: prompt rows are independent (per-row schedule generate.py:30-38, per-row top-k
     :130-133), so each rank samples a contiguous shard of rows and ONE all-gather of the
     [rows, L] int64 outputs ends the call.  Random streams are keyed by the global row index,
-    so the result does not depend on the number of ranks.
+    so the draws do not depend on the number of ranks (the forward's GEMM tiling does depend on
+    the rows per GPU, i.e. logits agree across rank counts to bf16 rounding noise, not bit for bit).
   * get_log_likelihood: every iteration's batch rows are dealt over ranks inside
     ``llada_amd.get_log_likelihood`` (rank/world_size arguments) and the per-iteration loss
     sums are all-reduced once.
