@@ -62,7 +62,8 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
             "dual" is an APPROXIMATION outside the reference (llada_amd.LLaDAModel only): the first step
             of each block runs the whole sequence and keeps every layer's keys and values; the block's
             other steps recompute only the block's positions against those cached keys and values of the
-            rest of the sequence (prefix and suffix), which are then one block stale.
+            rest of the sequence (prefix and suffix), which are then one block stale.  Only the block's own
+            positions are transfer candidates in this mode (a mask token left of the block is ignored).
     '''
     lib = _lib.load()
     device = torch.device(model.device)
