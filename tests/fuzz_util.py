@@ -25,9 +25,11 @@ def build_model():
     return ocfg, W, LLaDAModel(LLaDAWeights.from_numpy(cfg, W, "cuda"))
 
 
-def run(n_iter, seed, verbose=False, built=None):
+def run(n_iter, seed, verbose=False, built=None, cache=None):
     """Runs n_iter random cases; raises AssertionError (with the case description) on the first mismatch.
-    Returns the worst forward max-relative error seen."""
+    Returns the worst forward max-relative error seen.  ``cache="dual"``: the block-cached sampler (an approximation
+    of its own; its steps are replayed on a second cache with the calls generate() makes, so the epilogue and the
+    transfers are checked on bit-identical logits; only the block's positions are candidates there)."""
     from llada_amd import generate
     ocfg, W, model = built if built is not None else build_model()
     g = np.random.Generator(np.random.PCG64(seed))
@@ -70,7 +72,8 @@ def run(n_iter, seed, verbose=False, built=None):
         out = generate(model, torch.from_numpy(prompt), None if am is None else torch.from_numpy(am), steps=steps, gen_length=G,
                        block_length=bl, temperature=T, cfg_scale=cfg_scale, remasking=rule, mask_id=MASK_ID,
                        noise_fn=noise_fn if T else None, rand_fn=rand_fn if rule == "random" else None,
-                       step_callback=cb).cpu().numpy()
+                       step_callback=cb, cache=cache).cpu().numpy()
+        kv2 = model.kv_cache(2 * B if cfg_scale > 0 else B, L) if cache else None
         assert np.array_equal(out[:, :P], prompt), desc
         # (the mask token is an ordinary word of this small vocabulary: the model may predict it, and such a
         # position then stays masked, in the reference as here, so "no mask token left" is not asserted)
@@ -83,7 +86,7 @@ def run(n_iter, seed, verbose=False, built=None):
             # left of its end when an earlier position still holds the mask token), cond | uncond halves under guidance
             bs_, be_ = P + block * bl, P + (block + 1) * bl
             if t % spb == 0:
-                row_lo = 0 if (bs_ > 0 and (x_in[:, :bs_] == MASK_ID).any()) else bs_
+                row_lo = 0 if (cache is None and bs_ > 0 and (x_in[:, :bs_] == MASK_ID).any()) else bs_
             rows = (np.arange(B)[:, None] * L + np.arange(row_lo, be_)[None, :]).reshape(-1).astype(np.int32)
             fm = None if full_mask is None else torch.from_numpy(full_mask).cuda()
             lg = np.zeros((B, L, V), dtype=np.float32)
@@ -92,10 +95,19 @@ def run(n_iter, seed, verbose=False, built=None):
                 both = np.concatenate([x_in, un])
                 fm2 = torch.from_numpy(np.concatenate([full_mask, full_mask])).cuda()
                 rows2 = torch.from_numpy(np.concatenate([rows, rows + B * L])).cuda()
-                got = model.forward_rows(torch.from_numpy(both).cuda(), fm2, rows2).float().cpu().numpy()
+                if cache and t % spb:
+                    got = model.forward_block(torch.from_numpy(both[:, bs_:be_]).cuda(), fm2, L, bs_, kv2,
+                                              update_cache=False).float().cpu().numpy()
+                else:
+                    got = model.forward_rows(torch.from_numpy(both).cuda(), fm2, rows2, kv_cache=kv2).float().cpu().numpy()
                 lg.reshape(B * L, V)[rows] = osamp.cfg_combine(got[: rows.size], got[rows.size:], cfg_scale)
             else:
-                got = model.forward_rows(torch.from_numpy(x_in).cuda(), fm, torch.from_numpy(rows).cuda()).float().cpu().numpy()
+                if cache and t % spb:
+                    got = model.forward_block(torch.from_numpy(x_in[:, bs_:be_]).cuda(), fm, L, bs_, kv2,
+                                              update_cache=False).float().cpu().numpy()
+                else:
+                    got = model.forward_rows(torch.from_numpy(x_in).cuda(), fm, torch.from_numpy(rows).cuda(),
+                                             kv_cache=kv2).float().cpu().numpy()
                 lg.reshape(B * L, V)[rows] = got
             if t == 0 and cfg_scale == 0:
                 ref = forward(W, ocfg, x_in, full_mask, emulate_bf16=True).reshape(B * L, V)[rows]
@@ -105,6 +117,9 @@ def run(n_iter, seed, verbose=False, built=None):
             u = noise_log[t] if T else None
             rs = rand_log[t] if rule == "random" else None
             ox0, oconf = osamp.confidence_step(x_in, lg, MASK_ID, P + (block + 1) * bl, rule, T, u, rs)
+            if cache:
+                oconf[:, :bs_] = -np.inf
+                ox0[:, :bs_] = x_in[:, :bs_]
             live = ~np.isneginf(oconf)
             assert np.array_equal(np.isneginf(conf), np.isneginf(oconf)), (desc, t)
             assert np.array_equal(x0[live], ox0[live]), (desc, t)

@@ -33,3 +33,8 @@ def test_gemm_random_cases(lib, seed):
 def test_remask_random_cases(lib, seed):
     from tests.fuzz_util import run_rows
     assert run_rows(40, seed) == 40
+
+
+def test_generate_random_cases_block_cached(lib):
+    from tests.fuzz_util import run
+    assert run(25, 4, cache="dual") <= 2e-2

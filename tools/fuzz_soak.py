@@ -12,10 +12,11 @@ built = build_model()
 t0 = time.time()
 for seed in range(first, first + n_seeds):
     a = run(cases, seed, built=built)
+    run(cases // 2, seed + 10000, built=built, cache="dual")
     b = run_likelihood(cases, seed, built=built)
     c = run_attention(cases // 2, seed)
     run_gemm(cases, seed)
     run_rows(2 * cases, seed)
-    print(f"seed {seed}: generate forward max-rel {a:.2e}, likelihood {b:.1e}, attention {c:.2e}, GEMM exact, rows ok "
+    print(f"seed {seed}: generate forward max-rel {a:.2e}, likelihood {b:.1e}, attention {c:.2e}, GEMM exact, rows ok, cached generate ok "
           f"[{time.time() - t0:.0f} s]", flush=True)
 print("soak ok")
