@@ -1,3 +1,4 @@
+"""GEMM time against K at M = 3072 (pipelined and simple loop): per-K-step time shows the fixed fill / drain / write-out cost.  gemm_ksweep.py [N]"""
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from llada_amd import _lib

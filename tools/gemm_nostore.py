@@ -1,3 +1,4 @@
+"""The four projection shapes at M = 3072 with and without the write-out (test hook llada_gemm_no_store): cost of the epilogue stores."""
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from llada_amd import _lib

@@ -1,3 +1,4 @@
+"""Small-M GEMM sweep (weights warm): tile rows x forced split-K count, microseconds per launch against the weight-streaming bound.  gemm_splits.py [M]"""
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from llada_amd import _lib

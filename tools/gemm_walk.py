@@ -1,3 +1,4 @@
+"""Tile-walk sweep at M = 3072 (test hook llada_gemm_tile_walk): M tiles per band, XCD-aware block map on / off; TFLOP/s per shape."""
 import ctypes as C, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from llada_amd import _lib
