@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LLADA_ABI_VERSION 2
+#define LLADA_ABI_VERSION 3
 
 #define LLADA_OK 0
 #define LLADA_ERR_INVALID (-1)      /* bad argument (the Python host raises AssertionError/ValueError) */
@@ -257,6 +257,18 @@ typedef struct llada_remask_args {
  * cases, one workgroup holds a whole row on chip (vocabulary <= 131072). */
 size_t llada_rows_workspace_bytes(int32_t n_rows);
 int llada_remask_scores(const llada_remask_args* args, void* stream);
+
+/* llada_remask_scores for callers that cannot allocate device memory or bring a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments and results as llada_remask_scores (bit-identical); args->workspace / workspace_bytes are ignored:
+ * the statistics of the streamed row pieces go to a 2 MiB device array built into the library (one copy per
+ * GPU, held until the process ends), so the call allocates nothing.  At most LLADA_STATIC_REMASK_MAX_ROWS
+ * logits rows per call (LLADA_ERR_WORKSPACE beyond).  The first call on a device looks up the array's address
+ * (no allocation; make that call outside a graph capture).  All calls on one GPU share the array: calls that
+ * overlap on one GPU (different streams or threads) race; nothing in it needs clearing between calls (every
+ * entry a call reads was written by that call). */
+#define LLADA_STATIC_REMASK_MAX_ROWS 8192
+int llada_remask_scores_static(const llada_remask_args* args, void* stream);
 
 /* generate.py:130-134: per row b, the k = sched[b*sched_stride + step] largest confidences
  * (NaN ranks highest, ties go to the lower index) are transferred: x[b, i] = x0[b, i]. */

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLADA_HIP_LIB") or os.path.join(_HERE, "libllada_hip.so")   # override: A/B timing of two builds
 
-ABI_VERSION = 2     # LLADA_ABI_VERSION of include/llada_hip.h this binding was written for
+ABI_VERSION = 3     # LLADA_ABI_VERSION of include/llada_hip.h this binding was written for
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
 
@@ -19,6 +19,7 @@ REMASK = {"low_confidence": 0, "high_confidence": 1, "low_entropy": 2, "high_ent
 FLAG_LOGITS_EOS_INF, FLAG_CONF_EOS_EOT_INF, FLAG_CONF_FLOAT32 = 1, 2, 4
 EPI_PLAIN, EPI_RESIDUAL, EPI_ROPE_QKV, EPI_SWIGLU = 0, 1, 2, 3
 GEMM_W_TILED = 0x100
+STATIC_REMASK_MAX_ROWS = 8192
 
 vp = C.c_void_p
 
@@ -74,6 +75,7 @@ SIGNATURES = {
                                             vp, vp]),
     "llada_rows_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "llada_remask_scores": (C.c_int, [C.POINTER(RemaskArgs), vp]),
+    "llada_remask_scores_static": (C.c_int, [C.POINTER(RemaskArgs), vp]),
     "llada_topk_transfer": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp]),
     "llada_ll_mask": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_uint64, C.c_uint32,
                                 C.c_uint32, vp]),

@@ -8,6 +8,8 @@
 //   topk_transfer_kernel: per batch row, torch.topk + the masked scatter (:130-134) with k read
 //                        from the device schedule, so the step loop never synchronises the host.
 //   num_transfer_kernel : get_num_transfer_tokens (:22-40) on the block slice (:75-79).
+#include <mutex>
+
 #include "common.h"
 #include "philox.h"
 #include "rowregs.h"
@@ -617,6 +619,57 @@ extern "C" int llada_remask_scores(const llada_remask_args* args, void* stream) 
         hipLaunchKernelGGL(remask_rows_kernel<false>, dim3(a.n_rows), dim3(ROW_THREADS), ROW_LDS_BYTES, s, a);
     LLADA_CHECK_LAUNCH("remask_rows_kernel");
     return LLADA_OK;
+}
+
+// ---- llada_remask_scores without any allocation: the piece statistics live in this module's own device array ----
+// Room for LLADA_STATIC_REMASK_MAX_ROWS logits rows cut into RS_MAX_SPLITS pieces (2 MiB; every GPU the library
+// runs on holds its own copy until the process ends).  Host code must not use the array's name as an address (it is a
+// host-side stand-in): the device address is looked up once per device and only that pointer is handed to kernels.
+constexpr size_t SCRATCH_BYTES = (size_t)LLADA_STATIC_REMASK_MAX_ROWS * RS_MAX_SPLITS * (sizeof(RowPart) + sizeof(GumbelPart));
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_lock;
+void* scratch_ptr[MAX_DEVICES] = {};   // device address of `scratch` on each device, resolved on first use
+
+// Device address of this device's copy of `scratch` (hipGetSymbolAddress allocates nothing).
+int scratch_address(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        llada_set_error("remask_scores_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return LLADA_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> guard(scratch_lock);
+    if (scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            llada_set_error("remask_scores_static: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+            return LLADA_ERR_HIP;
+        }
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return LLADA_OK;
+}
+}  // namespace
+
+extern "C" int llada_remask_scores_static(const llada_remask_args* args, void* stream) {
+    LLADA_CHECK_ARG(args != nullptr, "remask_scores_static: null args");
+    if (args->n_rows > LLADA_STATIC_REMASK_MAX_ROWS) {
+        llada_set_error("remask_scores_static: n_rows=%d exceeds the built-in scratch of %d rows (use llada_remask_scores "
+                        "with a workspace)", args->n_rows, LLADA_STATIC_REMASK_MAX_ROWS);
+        return LLADA_ERR_WORKSPACE;
+    }
+    void* p = nullptr;
+    const int rc = scratch_address(&p);
+    if (rc != LLADA_OK) return rc;
+    llada_remask_args a = *args;
+    a.workspace = p;                  // the looked-up device address, never the array's name
+    a.workspace_bytes = SCRATCH_BYTES;
+    return llada_remask_scores(&a, stream);
 }
 
 int llada_rows_forced_splits = 0;   // test hook: 0 = automatic
