@@ -7,6 +7,11 @@ One "step" = one denoising step of the whole per-GPU batch: the non-causal forwa
 B*(P+G) tokens plus the fused remasking epilogue.  `value` = generated tokens/s of the whole job =
 N*B*G / (steps_total * time_per_step).
 
+`python bench.py --gpus N` launches its own N ranks (one process per GPU, RCCL) when no launcher has set
+WORLD_SIZE; under `python -m torch.distributed.run` it uses the ranks it is given.  `--total-batch T` switches to
+strong scaling: T prompts in all, dealt over the ranks (BASELINE configuration 3 is `--total-batch 64 --gen 512
+--block 64`).
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- dominant kernel = the gate/up projection GEMM (SwiGLU epilogue); achieved = its
                   algorithmic FLOPs per launch / its mean launch duration measured with HIP events
@@ -27,49 +32,77 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0
 
 
-def cpu_baseline(B, L, bl, cfg, seconds_hint=20.0):
-    """Oracle (numpy) on the host: TWO transformer layers of the 32 at the full token count, plus the
-    final norm / LM head on the block rows and the remasking epilogue; the step time is
-    extrapolated as 32 * layer + head + epilogue.  kind = "port" (the oracle restates the
-    reference's algorithm; the reference's own model code is not in its tree)."""
-    import numpy as np
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The reference's CPU path (BASELINE configuration 1: batch 1, gen_length 64, steps 64, block_length 32,
+    temperature 0, low_confidence, P = 128 -> 192 tokens per forward) timed on this host: oracle/model_torch.py
+    (torch-CPU restatement of the forward on all the threads torch has) + the oracle's numpy epilogue, full
+    logits for every position as the reference computes them (generate.py:92).  Bounded sample: the first few
+    denoising steps of the 64 (every step costs the same: no cache, fixed length), 32 layers per step cycling 4
+    distinct random weight sets (1.7 GB in bf16, far beyond any CPU cache) so that the host need not hold 15 GB.
+    kind = "port": the reference's own model code is not in its tree."""
+    import numpy as np
+    import torch
+
+    from oracle import model_torch as mt
     from oracle import sampler as osamp
     from oracle.model import LLaDAConfig as OCfg
-    from oracle.model import forward, rmsnorm
-    from oracle.bf16 import round_bf16
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    n_sample = 2                                    # layers actually run (about 11 s on 16 host threads)
-    ocfg = OCfg(d_model=cfg.d_model, n_layers=n_sample, n_heads=cfg.n_heads, mlp_hidden=cfg.mlp_hidden, vocab_size=cfg.vocab_size)
-    g = np.random.Generator(np.random.PCG64(0))
 
-    def w(n, k, s=0.02):
-        return round_bf16(g.standard_normal(size=(n, k), dtype=np.float32) * np.float32(s))
-
+    threads = torch.get_num_threads()
+    mode = mt.pick_mode()
     d, F, V = cfg.d_model, cfg.mlp_hidden, cfg.vocab_size
-    # a small embedding table (ids are folded into it) keeps the sample's memory bounded
-    W = {"wte": w(4096, d), "ln_f": np.ones(d, np.float32), "ff_out": w(V, d, 0.16)}
-    for i in range(n_sample):
+    n_sets = 4
+    ocfg = OCfg(d_model=d, n_layers=cfg.n_layers, n_heads=cfg.n_heads, mlp_hidden=F, vocab_size=V)
+    wdt = torch.bfloat16 if mode == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(0)
+    base = (torch.randn(F, d, generator=gen) * 0.02)
+
+    def w(n, k, shift, scale=1.0):
+        # timing only: every matrix is a rolled view of one random base (values N(0, 0.02^2), all distinct memory)
+        t = torch.roll(base, shifts=shift, dims=0)
+        t = t[:n, :k] if k <= d else t.t()[:n, :k]
+        return (t * scale).to(wdt).contiguous()
+
+    W = {"wte": w(4096, d, 1).to(torch.bfloat16), "ln_f": torch.ones(d), "ff_out": torch.cat([w(F, d, 3 + j, 8.0) for j in range(-(-V // F))])[:V].contiguous()}
+    for i in range(n_sets):
         p = f"blocks.{i}."
-        for name, shape in (("q_proj", (d, d)), ("k_proj", (d, d)), ("v_proj", (d, d)), ("attn_out", (d, d)),
-                            ("ff_proj", (F, d)), ("up_proj", (F, d)), ("ff_out", (d, F))):
-            W[p + name] = w(*shape)
-        W[p + "attn_norm"] = np.ones(d, np.float32)
-        W[p + "ff_norm"] = np.ones(d, np.float32)
-    ids = g.integers(0, 4096, size=(B, L), dtype=np.int64)
-    t0 = time.perf_counter()
-    h = forward(W, ocfg, ids, None, emulate_bf16=True, return_hidden=True)     # n_sample layers + final norm
-    t_layer = (time.perf_counter() - t0) / n_sample
-    t0 = time.perf_counter()
-    hb = h[:, L - bl:, :].reshape(B * bl, d)
-    logits = round_bf16(hb @ W["ff_out"].T).reshape(B, bl, V)
-    x = np.full((B, bl), cfg.mask_token_id, dtype=np.int64)
-    x0, conf = osamp.confidence_step(x, logits, cfg.mask_token_id, bl, "low_confidence")
-    osamp.topk_transfer(x, x0, conf, np.ones(B, dtype=np.int64))
-    t_head = time.perf_counter() - t0
-    t_step = cfg.n_layers * t_layer + t_head
-    return t_step, cores, (f"{n_sample} of {cfg.n_layers} layers at {B}x{L} tokens ({t_layer:.2f} s each) + LM head/epilogue on "
-                           f"{B * bl} rows ({t_head:.2f} s); step = {cfg.n_layers}*layer + head")
+        for j, (name, shape) in enumerate((("q_proj", (d, d)), ("k_proj", (d, d)), ("v_proj", (d, d)), ("attn_out", (d, d)),
+                                           ("ff_proj", (F, d)), ("up_proj", (F, d)), ("ff_out", (d, F)))):
+            W[p + name] = w(*shape, 17 * i + j + 20)
+        W[p + "attn_norm"] = torch.ones(d)
+        W[p + "ff_norm"] = torch.ones(d)
+    P, G, bl, mask_id = 128, 64, 32, cfg.mask_token_id
+    g = np.random.Generator(np.random.PCG64(1234))
+    x = np.full((1, P + G), mask_id, dtype=np.int64)
+    x[:, :P] = g.integers(0, 126000, size=(1, P))
+    times = []
+    t_all = time.perf_counter()
+    step = 0
+    while step < G // 2 and (step < 2 or time.perf_counter() - t_all < seconds_budget):   # steps of the first block
+        t0 = time.perf_counter()
+        logits = mt.forward(W, ocfg, torch.from_numpy(x), None, mode, layer_of=lambda i: i % n_sets)      # generate.py:92
+        x0, conf = osamp.confidence_step(x, logits.float().numpy(), mask_id, P + bl, "low_confidence")   # :97-128
+        osamp.topk_transfer(x, x0, conf, np.ones(1, dtype=np.int64))                                     # :130-134
+        times.append(time.perf_counter() - t0)
+        step += 1
+    t_step = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"value": round(1.0 / t_step, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "gemm_mode": mode,
+            "ms_per_step": round(1e3 * t_step, 1),
+            "sample": (f"BASELINE config 1 (batch 1, P=128, gen_length=64, steps=64, block_length=32, T=0, low_confidence): "
+                       f"{len(times)} of its 64 denoising steps, each one 32-layer torch-CPU forward over 192 tokens "
+                       f"({mode} GEMMs, {threads} threads, 4 weight sets cycled) + full-vocabulary numpy epilogue; "
+                       f"median step {t_step:.2f} s; 1 token per step")}
 
 
 def measured_ceilings(torch, device, M, N, K):
@@ -217,9 +250,47 @@ def likelihood_bench(args, torch, dist, model, cfg, world, rank, device, backend
                "config": {"workload": "get_log_likelihood(): mc_num=128, batch_size=32 (4 iterations), 384 tokens per row, rows of "
                                       "every iteration split over the ranks, all-reduce of the loss sums",
                           "layers": cfg.n_layers, "parallelism": f"dp{world}"},
+               "rccl_ranks": (dist.get_world_size() if world > 1 else 1) if backend == "nccl" else None,
+               "comm_backend": backend if world > 1 else None,
                "log_likelihood": round(val, 4),
                "mfma_util_layers": round(flops / (elapsed / K_) / 1e12 / PEAK_BF16_TFLOPS / world, 4)}
         print(json.dumps(rec), flush=True)
+
+
+def launch_ranks(n):
+    """Parent of a self-launched multi-GPU run: starts one child per rank (the same command line, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set) and waits for them.  This process never touches the GPU (it does not even import
+    torch).  Rank 0 inherits stdout, so its JSON line is this command's output.  Returns the exit status: non-zero
+    as soon as any rank fails (the others are then stopped)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    live = list(procs)
+    while live and status == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is not None:
+                live.remove(p)
+                if rc != 0:
+                    status = rc if rc > 0 else 1
+    for p in live:                      # a rank failed: stop the ranks this process started (by handle)
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return status
 
 
 def main():
@@ -227,7 +298,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=8, help="prompt rows per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="prompt rows per GPU (weak scaling, the default)")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="strong scaling: this many prompts in all, dealt over the ranks (overrides --batch)")
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--gen", type=int, default=256)
     ap.add_argument("--block", type=int, default=32)
@@ -238,6 +311,9 @@ def main():
                     help="likelihood: get_log_likelihood(mc_num=128, batch_size=32), prompt 256 + answer 128 tokens, the MC rows of "
                          "every iteration split over the ranks and the loss sums all-reduced (strong scaling; a step = one call)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))        # before anything here has touched the GPU
 
     import torch
     import torch.distributed as dist
@@ -250,7 +326,14 @@ def main():
     # LLADA_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
     # ranks (ranks then share devices and the timing reduce runs on the host); the real run is RCCL
     backend = os.environ.get("LLADA_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    if os.environ.get("LLADA_BENCH_ECHO_RANK"):
+        print(f"bench rank {rank} of {world}", file=sys.stderr, flush=True)
+    n_dev = torch.cuda.device_count()
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if backend == "nccl" and local_rank >= n_dev:
+        sys.exit(f"bench.py: rank {local_rank} has no GPU ({n_dev} visible); LLADA_BENCH_BACKEND=gloo lets ranks share devices")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
@@ -258,7 +341,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    # ranks of the collective backend actually in use (RCCL unless a rehearsal asked for gloo)
+    comm_ranks = dist.get_world_size() if world > 1 else 1
 
     cfg = LLaDAConfig(n_layers=args.layers)
     model = LLaDAModel(LLaDAWeights.random(cfg, device, seed=0))
@@ -271,12 +355,25 @@ def main():
             dist.destroy_process_group()
         return
 
-    B, P, G, bl = args.batch, args.prompt, args.gen, args.block
+    P, G, bl = args.prompt, args.gen, args.block
     L = P + G
     steps_total = G                                    # steps == gen_length (best-quality setting)
     gen = torch.Generator().manual_seed(1234)
-    prompts_all = torch.randint(0, 126000, (world * B, P), generator=gen, dtype=torch.long)
-    prompt = prompts_all[rank * B:(rank + 1) * B]
+    strong = args.total_batch > 0
+    if strong:
+        # a fixed set of prompts dealt over the ranks in contiguous, balanced shards (llada_amd.parallel)
+        from llada_amd.parallel import shard_bounds
+        total_rows = args.total_batch
+        if total_rows < world:
+            sys.exit(f"bench.py: --total-batch {total_rows} is fewer than one prompt per rank")
+        bounds = shard_bounds(total_rows, world)
+        row_lo, row_hi = bounds[rank], bounds[rank + 1]
+    else:
+        total_rows = world * args.batch
+        row_lo, row_hi = rank * args.batch, (rank + 1) * args.batch
+    B = row_hi - row_lo                                # this rank's rows
+    prompts_all = torch.randint(0, 126000, (total_rows, P), generator=gen, dtype=torch.long)
+    prompt = prompts_all[row_lo:row_hi]
 
     W_, K_ = args.warmup, args.steps
 
@@ -288,7 +385,7 @@ def main():
 
     elapsed = timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all,
                           on_start=lambda: lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L),
-                          row_offset=rank * B)
+                          row_offset=row_lo)
     tot_ms, n_s = C.c_double(0), C.c_int(0)
     lib.llada_gemm_profile_end(C.byref(tot_ms), C.byref(n_s))
     torch.cuda.synchronize()
@@ -297,7 +394,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / K_
-    tokens_per_s = world * B * G / (steps_total * ms_per_step * 1e-3)
+    tokens_per_s = total_rows * G / (steps_total * ms_per_step * 1e-3)
 
     if rank == 0:
         M = B * L
@@ -318,13 +415,18 @@ def main():
             with open(pmc_file) as fh:
                 traffic = json.load(fh).get("traffic_bytes")
         rec = {
-            "metric": "generated tokens/sec/node, LLaDA-8B gen256 steps256 blk32; ms/denoise step",
+            "metric": f"generated tokens/sec/node, LLaDA-8B gen{G} steps{steps_total} blk{bl}; ms/denoise step",
             "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": K_, "warmup": W_,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"LLaDA-8B generate(): {B} prompts/GPU x P={P}, gen_length={G}, steps={steps_total}, "
-                                   f"block_length={bl}, temperature 0, low_confidence (north-star batch 64 = 8 GPUs x 8)",
-                       "layers": cfg.n_layers, "rows_per_gpu": B, "seq_len": L, "parallelism": f"dp{world}"},
+            "config": {"workload": (f"LLaDA-8B generate(): {total_rows} prompts dealt over {world} GPU(s) ({B} on rank 0) x P={P}, "
+                                    if strong else f"LLaDA-8B generate(): {B} prompts/GPU x P={P}, ")
+                                   + f"gen_length={G}, steps={steps_total}, block_length={bl}, temperature 0, low_confidence"
+                                   + ("" if strong else " (north-star batch 64 = 8 GPUs x 8)"),
+                       "layers": cfg.n_layers, "rows_per_gpu": B, "total_rows": total_rows, "seq_len": L,
+                       "parallelism": f"dp{world}"},
+            "rccl_ranks": comm_ranks if backend == "nccl" else None, "comm_backend": backend if world > 1 else None,
             "step_tflops_executed": round(flops_step / 1e12, 3),
             "mfma_util_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_stream_kernel<6,SWIGLU> (gate/up projection, M = rows_per_gpu x seq_len)",
@@ -359,9 +461,7 @@ def main():
                 rec["block_cached"]["batch1_tokens_per_s"] = round(G / t1c, 1)
                 rec["block_cached"]["batch1_ms_per_step_mean"] = round(1e3 * t1c / steps_total, 3)
         if world == 1 and not args.no_cpu_baseline:      # the host baseline is reported at N = 1 only
-            t_step, cores, sample = cpu_baseline(B, L, bl, cfg)
-            rec["cpu_baseline"] = {"value": round(B * G / (steps_total * t_step), 4), "unit": "tokens/s", "cores": cores,
-                                   "kind": "port", "sample": sample, "ms_per_step": round(1e3 * t_step, 1)}
+            rec["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

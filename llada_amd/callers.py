@@ -6,8 +6,11 @@ they can be switched over by changing an import:
   * ``LLaDAModel`` / ``LLaDABaseModel`` -- the ``generate`` methods of the OpenCompass wrappers,
                                            /root/reference/opencompass/opencompass/models/dllm.py:371-405
                                            and :503-549 (left-padded batch encode, no attention mask,
-                                           decode of the last ``gen_length`` tokens, stop words), plus
-                                           the message converters :461-501.
+                                           decode of the last ``gen_length`` tokens, stop words).
+                                           The wrappers take inputs that are already in tokenizer form
+                                           (chat: a string or a list of {"role", "content"} messages per
+                                           request; base: a string per request); OpenCompass' PromptList
+                                           conversion (dllm.py:461-501) stays in OpenCompass.
 
 Only the parts that touch the sampler are restated; the OpenCompass base class (mmengine registry,
 template parsers, perplexity helpers that the reference itself disables at dllm.py:423) is not.
@@ -58,42 +61,6 @@ def chat(model_path, device="cuda", input_fn=input, print_fn=print):
         print_fn('-----------------------------------------------------------------------')
 
 
-def _convert_chat_messages(inputs, merge_role=True, skip_empty_prompt=True):
-    """dllm.py:461-488."""
-    outputs = []
-    for _input in inputs:
-        messages = []
-        if isinstance(_input, str):
-            messages.append({'role': 'user', 'content': _input})
-        else:
-            for item in _input:
-                if skip_empty_prompt and not item['prompt']:
-                    continue
-                role = {'HUMAN': 'user', 'BOT': 'assistant', 'SYSTEM': 'system'}[item['role']]
-                messages.append({'role': role, 'content': item['prompt']})
-        if merge_role:
-            merged = []
-            for item in messages:
-                if merged and merged[-1]['role'] == item['role']:
-                    merged[-1]['content'] += '\n' + item['content']
-                else:
-                    merged.append(item)
-            messages = merged
-        outputs.append(messages)
-    return outputs
-
-
-def _convert_base_messages(inputs):
-    """dllm.py:491-501."""
-    outputs = []
-    for _input in inputs:
-        if isinstance(_input, str):
-            outputs.append(_input)
-        else:
-            outputs.append(''.join(item['prompt'] for item in _input))
-    return outputs
-
-
 class LLaDAModel:
     """The sampler-facing part of dllm.py:69-405 (chat-template model)."""
 
@@ -119,7 +86,8 @@ class LLaDAModel:
         return len(self.tokenizer.encode(prompt))                                          # dllm.py:360-369
 
     def _prompts(self, inputs):
-        messages = _convert_chat_messages(inputs)                                          # dllm.py:373-374
+        """One chat-template prompt per request (dllm.py:375-377); a bare string is one user message."""
+        messages = [[{"role": "user", "content": m}] if isinstance(m, str) else list(m) for m in inputs]
         return [self.tokenizer.apply_chat_template(m_i, add_generation_prompt=True, tokenize=False) for m_i in messages]
 
     def _sample(self, prompt_texts):
@@ -149,7 +117,9 @@ class LLaDABaseModel(LLaDAModel):
     """dllm.py:503-554 (base model: plain concatenated prompt, stop-word trimming)."""
 
     def _prompts(self, inputs):
-        return _convert_base_messages(inputs)                                              # dllm.py:509-510
+        if not all(isinstance(m, str) for m in inputs):
+            raise TypeError("LLaDABaseModel takes one prompt string per request")
+        return list(inputs)
 
     def generate(self, inputs, max_out_len=None):
         responses = self._sample(self._prompts(inputs))
@@ -163,5 +133,4 @@ class LLaDABaseModel(LLaDAModel):
         return responses
 
     def get_token_len(self, prompt, add_special_tokens=True):
-        m = _convert_base_messages([prompt])[0]                                            # dllm.py:551-554
-        return len(self.tokenizer(m, add_special_tokens=add_special_tokens)['input_ids'])
+        return len(self.tokenizer(prompt, add_special_tokens=add_special_tokens)['input_ids'])   # dllm.py:551-554

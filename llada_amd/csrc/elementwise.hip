@@ -11,7 +11,7 @@ __global__ void embed_kernel(const bf16_t* __restrict__ wte, const int64_t* __re
     const int chunks = d / 8;
     for (int64_t m = blockIdx.x; m < n_tokens; m += gridDim.x) {
         int64_t id = ids[m];
-        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // host validates; never read out of bounds
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // memory safety only: the Python host (check_token_ids) rejects such ids before the call
         const u32x4* src = (const u32x4*)(wte + id * d);
         u32x4* dst = (u32x4*)(out + m * d);
         for (int c = threadIdx.x; c < chunks; c += blockDim.x) dst[c] = src[c];
@@ -24,7 +24,7 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ in, const int32_t*
     const int chunks = d / 8;
     for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
         int64_t src_row = rows[r];
-        src_row = src_row < 0 ? 0 : (src_row >= n_in ? n_in - 1 : src_row);  // host validates; never read out of bounds
+        src_row = src_row < 0 ? 0 : (src_row >= n_in ? n_in - 1 : src_row);  // memory safety only: the row lists are built by the library's own host code
         const u32x4* src = (const u32x4*)(in + src_row * d);
         u32x4* dst = (u32x4*)(out + r * d);
         for (int c = threadIdx.x; c < chunks; c += blockDim.x) dst[c] = src[c];

@@ -105,6 +105,10 @@ __global__ void __launch_bounds__(ROW_THREADS) masked_ce_kernel(const bf16_t* __
     const float tot = block_sum16(row.sum_exp(m), red[1], lane, wave);
     if (tid == 0) {
         const int64_t tgt = seq[pos];
+        if (tgt < 0 || tgt >= V) {       // F.cross_entropy raises for such a target; here the sum turns NaN (no read outside the row)
+            row_loss[r] = NAN;
+            return;
+        }
         float lt = bf16_to_f32(lc[tgt]);
         if (lu) lt = cfg_combine(lt, bf16_to_f32(lu[tgt]), cfg1);
         float logp = (lt - m) - logf(tot);
@@ -150,11 +154,15 @@ __global__ void __launch_bounds__(256) ce_merge_kernel(const bf16_t* __restrict_
             float M = p[0].m, S = p[0].s;
             for (int k = 1; k < splits; ++k) rs_merge(M, S, p[k].m, p[k].s);
             const int64_t tgt = seq[pos];
-            float lt = bf16_to_f32(logits[(size_t)r * V + tgt]);
-            if (uncond) lt = cfg_combine(lt, bf16_to_f32(uncond[(size_t)r * V + tgt]), cfg1);
-            float logp = (lt - M) - logf(S);
-            if (round_ce) logp = round_bf16(logp);
-            loss = -logp / p_mask_rows[pos / l];
+            if (tgt < 0 || tgt >= V) {   // F.cross_entropy raises for such a target; here the sum turns NaN
+                loss = NAN;
+            } else {
+                float lt = bf16_to_f32(logits[(size_t)r * V + tgt]);
+                if (uncond) lt = cfg_combine(lt, bf16_to_f32(uncond[(size_t)r * V + tgt]), cfg1);
+                float logp = (lt - M) - logf(S);
+                if (round_ce) logp = round_bf16(logp);
+                loss = -logp / p_mask_rows[pos / l];
+            }
         }
         row_loss[r] = loss;
         acc += (double)loss;

@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .model import LLaDAModel
+from .model import LLaDAModel, check_token_ids
 
 EOS_ID = 126081   # generate.py:95,101
 EOT_ID = 126348   # generate.py:101
@@ -84,6 +84,8 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         raise NotImplementedError(remasking)                                              # :122-123
 
     fast = isinstance(model, LLaDAModel)
+    if fast:
+        check_token_ids(prompt, model.cfg.vocab_size, mask_id, "prompt")   # the reference's embedding would raise
     if cache not in (None, "dual"):
         raise NotImplementedError(f"cache={cache!r}")
     if cache is not None and not fast:

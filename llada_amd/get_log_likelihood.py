@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib, rng
-from .model import LLaDAModel
+from .model import LLaDAModel, check_token_ids
 from .parallel import combine_loss_sums, shard_bounds
 
 
@@ -59,7 +59,7 @@ def forward_process(batch, prompt_index, mask_id, *, k=None, perms=None, seed=0,
 @torch.no_grad()
 def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_scale=0., mask_id=126336, *,
                        seed=0, k_fn=None, perm_fn=None, round_ce_bf16=True, rank=0, world_size=1,
-                       process_group=None):
+                       process_group=None, return_loss_sums=False):
     '''
     Args (get_log_likelihood.py:48-59):
         model: Mask predictor.  prompt: tensor (l1).  answer: tensor (l2).
@@ -72,10 +72,12 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
             logits (True reproduces the reference; False keeps float32).
         rank / world_size / process_group: data-parallel split of every iteration's batch_size
             rows over ranks; the per-iteration loss sums are all-reduced once at the end.
+        return_loss_sums: return this rank's per-iteration sums of CE / p_mask (float64 device tensor
+            [mc_num // batch_size]) instead of reducing them: the rank's contribution before the all-reduce.
     '''
     lib = _lib.load()
     device = torch.device(model.device)
-    seq = torch.concatenate([prompt.to(device), answer.to(device)])[None, :]                    # :61
+    seq = torch.concatenate([prompt.to(device), answer.to(device)])[None, :].to(torch.long)     # :61
     seq = seq.repeat((batch_size, 1)).contiguous()                                              # :62
     l1, l = len(prompt), seq.shape[1]
     T = l - l1
@@ -84,6 +86,14 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
     if n_iter == 0:
         raise ZeroDivisionError("division by zero")                                             # :77 with no iteration
     fast = isinstance(model, LLaDAModel)
+    if fast:
+        check_token_ids(seq[0], model.cfg.vocab_size, mask_id, "prompt + answer")   # F.cross_entropy / the embedding would raise
+        # A literal mask token in the prompt or the answer is part of `mask_index` in the reference
+        # (get_log_likelihood.py:68 compares the whole row), so it adds a CE / p_mask term there.  The compacted
+        # fast path below only looks at the answer positions the masking itself chose: take the full-logits
+        # path (every position of every row, as the reference) in that rare case.  One host read per call.
+        if bool((seq[0] == mask_id).any().item()):
+            fast = False
 
     # this rank's contiguous share of the batch rows
     bounds = shard_bounds(batch_size, world_size)
@@ -149,6 +159,8 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
                                            cond.shape[-1], noisy.data_ptr(), seq_loc.data_ptr(), b_loc, l, mask_id,
                                            pmask_t[it].data_ptr(), 1 if round_ce_bf16 else 0, row_loss.data_ptr(),
                                            loss_sums[it:].data_ptr(), ws.data_ptr(), ws.numel(), stream))  # :72
+    if return_loss_sums:
+        return loss_sums
     return combine_loss_sums(loss_sums, batch_size, world_size, process_group)
 
 
@@ -174,6 +186,26 @@ def get_log_likelihood_many(model, pairs, mc_num=128, batch_size=16, cfg_scale=0
     if seeds is None:
         seeds = list(range(len(pairs)))
     assert len(seeds) == len(pairs)
+    # ids outside the vocabulary raise as in the reference; a request that contains a literal mask token needs
+    # the full-logits path of get_log_likelihood (get_log_likelihood.py:68 counts it) and is run on its own
+    special = []
+    for i, (prompt, answer) in enumerate(pairs):
+        both = torch.cat([prompt.reshape(-1), answer.reshape(-1)]).to(device)
+        check_token_ids(both, model.cfg.vocab_size, mask_id, f"request {i}")
+        if bool((both == mask_id).any().item()):
+            special.append(i)
+    if special:
+        keep = [i for i in range(len(pairs)) if i not in special]
+        out = [None] * len(pairs)
+        if keep:
+            rest = get_log_likelihood_many(model, [pairs[i] for i in keep], mc_num, batch_size, cfg_scale, mask_id,
+                                           seeds=[seeds[i] for i in keep], max_rows=max_rows, round_ce_bf16=round_ce_bf16)
+            for i, v in zip(keep, rest):
+                out[i] = v
+        for i in special:
+            out[i] = get_log_likelihood(model, pairs[i][0], pairs[i][1], mc_num, batch_size, cfg_scale, mask_id,
+                                        seed=seeds[i], round_ce_bf16=round_ce_bf16)
+        return out
     stream = _lib.stream_ptr()
     # one group = the batch_size rows of one iteration of one request
     groups = []

@@ -18,6 +18,21 @@ class ModelOutput:
         self.logits = logits
 
 
+def check_token_ids(ids, vocab_size, mask_id=None, what="input_ids"):
+    """The reference's embedding lookup and F.cross_entropy raise for ids outside [0, vocab) (an IndexError from
+    torch); the kernels would clamp them instead, so the drop-ins check once per call, outside the step loop
+    (one host read)."""
+    if mask_id is not None and not (0 <= int(mask_id) < vocab_size):
+        raise IndexError(f"mask_id {mask_id} is outside the vocabulary of {vocab_size} entries")
+    if ids.numel() == 0:
+        return
+    lo, hi = torch.aminmax(ids)
+    lo, hi = int(lo.item()), int(hi.item())
+    if lo < 0 or hi >= vocab_size:
+        raise IndexError(f"{what}: token id {lo if lo < 0 else hi} is outside the vocabulary of {vocab_size} entries "
+                         "(index out of range)")
+
+
 class LLaDAModel:
     def __init__(self, weights: LLaDAWeights):
         self.lib = _lib.load()

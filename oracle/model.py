@@ -101,33 +101,44 @@ def attention(q, k, v, key_mask, emulate):
     return _r(o, emulate)
 
 
+def block(x, Wl, cfg, cos, sin, attention_mask=None, emulate_bf16=True, kv_out=None):
+    """One pre-norm transformer block on x [B, L, d] -> [B, L, d].  ``Wl`` holds the block's weights under the
+    bare names attn_norm, q_proj, k_proj, v_proj, attn_out, ff_norm, ff_proj, up_proj, ff_out."""
+    em = emulate_bf16
+    B, L, _ = x.shape
+    H, D = cfg.n_heads, cfg.head_dim
+    h = rmsnorm(x, Wl["attn_norm"], cfg.rms_eps, em)
+    q = _r(h @ Wl["q_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
+    k = _r(h @ Wl["k_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
+    v = _r(h @ Wl["v_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
+    q = apply_rope(q, cos, sin, em)
+    k = apply_rope(k, cos, sin, em)
+    if kv_out is not None:
+        kv_out.append((k.copy(), v.copy()))
+    a = attention(q, k, v, attention_mask, em).transpose(0, 2, 1, 3).reshape(B, L, H * D)
+    x = _r(x + _r(a @ Wl["attn_out"].T, em), em)
+    h = rmsnorm(x, Wl["ff_norm"], cfg.rms_eps, em)
+    g = _r(h @ Wl["ff_proj"].T, em)
+    u = _r(h @ Wl["up_proj"].T, em)
+    act = _r(g / (np.float32(1.0) + np.exp(-g)), em)     # silu
+    return _r(x + _r(_r(act * u, em) @ Wl["ff_out"].T, em), em)
+
+
+LAYER_KEYS = ("attn_norm", "q_proj", "k_proj", "v_proj", "attn_out", "ff_norm", "ff_proj", "up_proj", "ff_out")
+
+
 def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, return_hidden=False, kv_out=None):
     """ids int64 [B, L] -> logits float32 [B, L, V] (bf16 values when emulate_bf16).  ``kv_out`` (a list)
     receives every layer's rotated keys and values (k, v), each [B, H, L, D], for forward_block."""
     em = emulate_bf16
     ids = np.asarray(ids)
     B, L = ids.shape
-    H, D = cfg.n_heads, cfg.head_dim
     x = W["wte"][ids].astype(np.float32)                     # [B, L, d]
-    cos, sin = rope_tables(L, D, cfg.rope_theta)
+    cos, sin = rope_tables(L, cfg.head_dim, cfg.rope_theta)
     nl = cfg.n_layers if n_layers is None else n_layers
     for i in range(nl):
         p = f"blocks.{i}."
-        h = rmsnorm(x, W[p + "attn_norm"], cfg.rms_eps, em)
-        q = _r(h @ W[p + "q_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
-        k = _r(h @ W[p + "k_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
-        v = _r(h @ W[p + "v_proj"].T, em).reshape(B, L, H, D).transpose(0, 2, 1, 3)
-        q = apply_rope(q, cos, sin, em)
-        k = apply_rope(k, cos, sin, em)
-        if kv_out is not None:
-            kv_out.append((k.copy(), v.copy()))
-        a = attention(q, k, v, attention_mask, em).transpose(0, 2, 1, 3).reshape(B, L, H * D)
-        x = _r(x + _r(a @ W[p + "attn_out"].T, em), em)
-        h = rmsnorm(x, W[p + "ff_norm"], cfg.rms_eps, em)
-        g = _r(h @ W[p + "ff_proj"].T, em)
-        u = _r(h @ W[p + "up_proj"].T, em)
-        act = _r(g / (np.float32(1.0) + np.exp(-g)), em)     # silu
-        x = _r(x + _r(_r(act * u, em) @ W[p + "ff_out"].T, em), em)
+        x = block(x, {k: W[p + k] for k in LAYER_KEYS}, cfg, cos, sin, attention_mask, em, kv_out)
     hf = rmsnorm(x, W["ln_f"], cfg.rms_eps, em)
     if return_hidden:
         return hf

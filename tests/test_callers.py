@@ -1,4 +1,4 @@
-"""The callers restated in llada_amd.callers (chat.py:7-40; dllm.py:371-405, 461-549) and the local
+"""The callers restated in llada_amd.callers (chat.py:7-40; dllm.py:371-405, 503-549) and the local
 checkpoint loader.  Host logic runs on the CPU; the end-to-end cases need the GPU."""
 import json
 
@@ -50,18 +50,6 @@ class ToyTokenizer:
 
     def batch_decode(self, rows, skip_special_tokens=False):
         return [self.decode(r, skip_special_tokens) for r in rows]
-
-
-def test_message_converters():
-    from llada_amd.callers import _convert_base_messages, _convert_chat_messages
-    inputs = ["plain question",
-              [{"role": "SYSTEM", "prompt": "be brief"}, {"role": "HUMAN", "prompt": "a"}, {"role": "HUMAN", "prompt": "b"},
-               {"role": "BOT", "prompt": ""}, {"role": "BOT", "prompt": "c"}]]
-    chat = _convert_chat_messages(inputs)
-    assert chat[0] == [{"role": "user", "content": "plain question"}]
-    assert chat[1] == [{"role": "system", "content": "be brief"}, {"role": "user", "content": "a\nb"},
-                       {"role": "assistant", "content": "c"}]
-    assert _convert_base_messages(inputs) == ["plain question", "be briefabc"]
 
 
 def test_checkpoint_loader_roundtrip(tmp_path):
@@ -128,10 +116,13 @@ def test_opencompass_wrappers(lib, small_full_vocab_model):
     model, tok = small_full_vocab_model, ToyTokenizer()
     kw = dict(model=model, tokenizer=tok, gen_steps=16, gen_length=16, gen_blocksize=8, batch_size_=3,
               diff_confidence_eos_eot_inf=True, diff_logits_eos_inf=True)
-    inputs = ["short", "a much longer question than the first", [{"role": "HUMAN", "prompt": "x"}, {"role": "BOT", "prompt": "y"}]]
-    chat_out = LLaDAModel(**kw).generate(inputs, max_out_len=16)
+    inputs = ["short", "a much longer question than the first", "xy"]
+    chat_inputs = inputs[:2] + [[{"role": "user", "content": "x"}, {"role": "assistant", "content": "y"}]]
+    chat_out = LLaDAModel(**kw).generate(chat_inputs, max_out_len=16)
     assert len(chat_out) == 3 and all(isinstance(r, str) for r in chat_out)
     base = LLaDABaseModel(stop_words=["q", "zz"], **kw)
+    with pytest.raises(TypeError):
+        base.generate(chat_inputs, max_out_len=16)
     out = base.generate(inputs, max_out_len=16)
     assert len(out) == 3 and all("q" not in r for r in out)
     # same tokens as generate() on the left-padded batch without an attention mask (dllm.py:516-530)
@@ -146,3 +137,63 @@ def test_opencompass_wrappers(lib, small_full_vocab_model):
     assert base.get_token_len("abc") == 4 and base.get_token_len("abc", add_special_tokens=False) == 3
     with pytest.raises(NotImplementedError):
         base.get_ppl(["x"])
+
+
+class ProtocolModel:
+    """A foreign model that only honours the reference's protocol (generate.py:60,88,92); its logits are a
+    closed-form function of the call number, regenerated on the oracle's side."""
+
+    def __init__(self, seed, device):
+        self.device, self.seed, self.calls = torch.device(device), seed, 0
+
+    def logits_np(self, shape):
+        from tests.golden_util import fake_model_logits
+        lg = fake_model_logits(self.seed, self.calls, shape + (VOCAB,))
+        self.calls += 1
+        return lg
+
+    def __call__(self, x, attention_mask=None):
+        class Out:
+            pass
+        o = Out()
+        o.logits = torch.from_numpy(self.logits_np(tuple(x.shape))).to(self.device).to(torch.bfloat16)
+        return o
+
+
+VOCAB = 126464
+
+
+@pytest.mark.gpu
+def test_wrappers_against_the_oracle_sampler(lib):
+    """The OpenCompass-style wrapper and chat_turn on a foreign protocol model against the ORACLE's sampler
+    (oracle/sampler.py::generate, pinned to the reference's recorded runs) fed the same logits: an independent
+    check of the prompt assembly, the left padding without attention mask, both EOS flags and the decode of
+    the last gen_length ids."""
+    from oracle import sampler as osamp
+    from oracle.bf16 import round_bf16
+    from llada_amd.callers import LLaDABaseModel, chat_turn
+    tok = ToyTokenizer()
+
+    class NpModel:
+        def __init__(self, seed):
+            self.inner = ProtocolModel(seed, "cpu")
+
+        def __call__(self, x, attention_mask=None):
+            return round_bf16(self.inner.logits_np(tuple(x.shape)))
+
+    inputs = ["short", "a much longer question than the first", "xy"]
+    base = LLaDABaseModel(model=ProtocolModel(41, "cuda"), tokenizer=tok, gen_steps=8, gen_length=16, gen_blocksize=8,
+                          batch_size_=3, diff_confidence_eos_eot_inf=True, diff_logits_eos_inf=True)
+    got = base.generate(inputs, max_out_len=16)
+    tok.padding_side = "left"
+    prompt = tok.batch_encode_plus(inputs, padding=True)["input_ids"].numpy()
+    want = osamp.generate(NpModel(41), prompt, None, steps=8, gen_length=16, block_length=8, temperature=0., cfg_scale=0.,
+                          remasking="low_confidence", mask_id=MASK_ID, logits_eos_inf=True, confidence_eos_eot_inf=True)
+    assert got == [tok.decode(want[i, -16:], skip_special_tokens=True) for i in range(3)]
+
+    ans, ctx = chat_turn(ProtocolModel(43, "cuda"), tok, None, "hi there", gen_length=16, steps=16, block_length=8)
+    first = np.array([tok(tok.apply_chat_template([{"role": "user", "content": "hi there"}]))["input_ids"]])
+    want = osamp.generate(NpModel(43), first, None, steps=16, gen_length=16, block_length=8, temperature=0., cfg_scale=0.,
+                          remasking="low_confidence", mask_id=MASK_ID)
+    assert ans == tok.decode(want[0, first.shape[1]:], skip_special_tokens=True)
+    assert np.array_equal(ctx.cpu().numpy()[0], want[0][want[0] != EOS_ID])

@@ -15,15 +15,6 @@ torch = pytest.importorskip("torch")
 MASK_ID = 126336
 
 
-@pytest.fixture(scope="module")
-def model8b(lib):
-    from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights
-    m = LLaDAModel(LLaDAWeights.random(LLaDAConfig(), "cuda", seed=0))
-    yield m
-    del m
-    torch.cuda.empty_cache()
-
-
 def prompts(B, P, seed=1234):
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, 126000, (B, P), generator=g, dtype=torch.long)

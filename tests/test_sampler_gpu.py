@@ -129,8 +129,18 @@ def test_remask_step_teacher_forced(lib, case, sampler_z):
                                            case["eos_inf"], case["conf_inf"])
         assert_x0(x0, ox0, oconf, xs[t])
         compare_conf(conf, oconf, exact=case["remasking"] == "random", abs_tol=4e-7 if entropy else 0.0)
-        if not entropy:   # the golden entropy values carry torch's CPU-only log_softmax rounding
+        if not entropy:
             compare_conf(conf, conf_ref[t], exact=case["remasking"] == "random")
+        else:
+            # The reference's recorded entropy scores were computed on the CPU, where torch's bf16 log_softmax keeps
+            # the row's log-sum-exp in a bf16 scratch; the kernel keeps it in float32, as a GPU run of the reference
+            # does.  That shifts every log-probability by at most half a bf16 step of the log-sum-exp (<= log V =
+            # 6.2 here: 2^-6), and the entropy by as much, before its own rounding to bf16 (another 2^-6 below 8):
+            # bounded deviation instead of equality, same -inf / NaN pattern.
+            ref_c = conf_ref[t].astype(np.float32)
+            assert np.array_equal(np.isneginf(conf), np.isneginf(ref_c)) and np.array_equal(np.isnan(conf), np.isnan(ref_c))
+            fin = np.isfinite(ref_c)
+            assert np.abs(conf[fin] - ref_c[fin]).max(initial=0.0) <= 2.0 ** -5
         # top-k transfer on the reference's own confidence tensor
         xt = dev(xs[t].copy())
         sched = dev(ks[t].astype(np.int32).reshape(B, 1))
@@ -208,8 +218,8 @@ def test_remask_full_vocab(lib):
         compare_conf(conf, oconf, exact=False)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3])
-@pytest.mark.parametrize("remasking", ["low_confidence", "high_confidence", "random"])
+@pytest.mark.parametrize("remasking,flags", [(r, f) for r in ("low_confidence", "high_confidence", "random") for f in (0, 1, 2, 3)]
+                         + [("low_entropy", 0), ("high_entropy", 0), ("low_entropy", 1), ("high_entropy", 3)])
 def test_remask_full_vocab_planted_rows(lib, remasking, flags):
     """Full-vocabulary rows built to hit the seams of the row kernels: the maximum repeated in far-apart
     places (the first index must win whichever piece finds it), the maximum on EOS / on EoT (removed
@@ -243,7 +253,9 @@ def test_remask_full_vocab_planted_rows(lib, remasking, flags):
             ox0, oconf = osamp.confidence_step(x, lg.copy(), MASK_ID, L, remasking, 0.0, None, rs, bool(flags & 1),
                                                bool(flags & 2))
             assert_x0(x0, ox0, oconf, x)
-            compare_conf(conf, oconf, exact=remasking == "random")
+            # entropy rules: a -inf logit makes the reference's score NaN (generate.py:113,118: -inf * 0), which
+            # torch.topk ranks highest; finite scores are float32 sums of 126464 bf16 terms (summation order)
+            compare_conf(conf, oconf, exact=remasking == "random", abs_tol=2e-6 if "entropy" in remasking else 0.0)
     finally:
         ROW_MODE["splits"] = modes[0]
 
