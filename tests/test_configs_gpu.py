@@ -139,7 +139,7 @@ def test_guided_sampled_generate_gen1024_block128(model8b):
         xs = []
 
         def cbn(block, step, x, x0, conf):
-            xs.append(x.clone())
+            xs.append(torch.stack([x, x0]))     # the committed tokens and every position's sampled candidate
             if len(xs) == n:
                 raise StopGenerate
         with pytest.raises(StopGenerate):
@@ -148,7 +148,7 @@ def test_guided_sampled_generate_gen1024_block128(model8b):
         return torch.stack(xs)
     a, b, c = run(11), run(11), run(12)
     assert torch.equal(a, b) and not torch.equal(a, c)
-    assert ((a == MASK_ID).sum(dim=(1, 2)).cpu().numpy() == G - np.arange(1, 4)).all()
+    assert ((a[:, 0] == MASK_ID).sum(dim=(1, 2)).cpu().numpy() == G - np.arange(1, 4)).all()
 
 
 def test_likelihood_mc128_batch32(model8b):
@@ -209,9 +209,15 @@ def test_generate_row_shards_match_the_whole_batch(lib, remasking, temperature):
     bounds = shard_bounds(8, 3)
     pieces = [generate(model, prompt[bounds[r]:bounds[r + 1]], row_offset=bounds[r], **kw) for r in range(3)]
     assert torch.equal(torch.cat(pieces), whole)
-    if temperature > 0 or remasking == "random":
-        other = generate(model, prompt[4:8], row_offset=0, **kw)      # the wrong offset draws other streams
-        assert not torch.equal(other, whole[4:8])
+    # step by step too (the table model's temperature-0 tokens do not depend on the order of unmasking, the
+    # intermediate states do), and the wrong offset draws other streams
+    def states(p, off):
+        xs = []
+        generate(model, p, row_offset=off, step_callback=lambda b, s, x, x0, c: xs.append(x.clone()), **kw)
+        return torch.stack(xs)
+    mid = states(prompt, 0)
+    assert torch.equal(states(prompt[4:8], 4), mid[:, 4:8])
+    assert not torch.equal(states(prompt[4:8], 0), mid[:, 4:8])
 
 
 def test_likelihood_rank_sums_add_up_exactly(lib):
