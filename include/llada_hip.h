@@ -220,6 +220,15 @@ int llada_forward_block(const llada_config* cfg, const llada_weights* w, const i
 int llada_num_transfer_tokens(const int64_t* x, int32_t B, int32_t L, int32_t block_start, int32_t block_end,
                               int64_t mask_id, int32_t steps, int32_t* sched, void* stream);
 
+/* add_gumbel_noise (generate.py:8-19) as a map of its own, for callers that import the helper: out[r, v] =
+ * exp(logits[r, v]) / (-log u[r, v]) ** temperature in float64, logits / out [n_rows, vocab] float64 (the
+ * reference converts to float64 first, :16), row r = batch row r / L, position r % L.  noise [n_rows, vocab]
+ * float64 uniforms replace torch.rand_like (:17), or NULL = the library's Philox stream with the counters
+ * llada_remask_scores uses for (seed, step, row_offset), so argmax(out) is that call's candidate token.
+ * generate() never calls this: its epilogue ranks the same scores in registers. */
+int llada_add_gumbel_noise(const double* logits, const double* noise, double temperature, double* out, int64_t n_rows,
+                           int32_t vocab, int32_t L, uint64_t seed, uint32_t step, uint32_t row_offset, void* stream);
+
 typedef struct llada_remask_args {
     const void* logits;        /* [n_rows, vocab] bf16 (the conditional half under CFG) */
     const void* uncond_logits; /* [n_rows, vocab] bf16 or NULL; generate.py:89-90 combine is fused */

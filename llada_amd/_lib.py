@@ -73,6 +73,8 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, C.c_size_t, vp]),
     "llada_num_transfer_tokens": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                             vp, vp]),
+    "llada_add_gumbel_noise": (C.c_int, [vp, vp, C.c_double, vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
+                                         C.c_uint32, vp]),
     "llada_rows_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "llada_remask_scores": (C.c_int, [C.POINTER(RemaskArgs), vp]),
     "llada_remask_scores_static": (C.c_int, [C.POINTER(RemaskArgs), vp]),

@@ -517,7 +517,52 @@ __global__ void __launch_bounds__(256) num_transfer_kernel(const int64_t* __rest
     for (int s = tid; s < steps; s += 256) sched[(size_t)b * steps + s] = base + (s < rem ? 1 : 0);
 }
 
+// add_gumbel_noise of generate.py:8-19 as a stand-alone map (the sampler itself never materialises it: the
+// fused epilogue ranks l - T*log(-log u) in registers): out = exp(l) / (-log u)^T in float64.  One thread per
+// 8 consecutive entries, the same Philox counters as the fused kernels, so argmax(out) is the epilogue's x0.
+__global__ void __launch_bounds__(256) gumbel_noise_kernel(const double* __restrict__ logits, const double* __restrict__ noise,
+                                                           double temp, double* __restrict__ out, int64_t n_rows, int V,
+                                                           int L, uint64_t seed, uint32_t step, uint32_t row_offset) {
+    const int chunks = V / 8;
+    uint32_t k0, k1;
+    philox_key(seed, LLADA_STREAM_GUMBEL, k0, k1);
+    const int64_t total = n_rows * chunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        const uint32_t b = (uint32_t)(r / L), col = (uint32_t)(r % L);
+        const size_t base = (size_t)r * V + (size_t)c * 8;
+        double u[8];
+        if (noise) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = noise[base + e];
+        } else {
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) {
+                const Philox4 ph = philox4x32_10((uint32_t)(c * 4 + h2), col, row_offset + b, step, k0, k1);
+                u[2 * h2] = u53(ph.v[0], ph.v[1]);
+                u[2 * h2 + 1] = u53(ph.v[2], ph.v[3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[base + e] = exp(logits[base + e]) / pow(-log(u[e]), temp);   // generate.py:17-19
+    }
+}
+
 }  // namespace
+
+extern "C" int llada_add_gumbel_noise(const double* logits, const double* noise, double temperature, double* out,
+                                      int64_t n_rows, int32_t vocab, int32_t L, uint64_t seed, uint32_t step,
+                                      uint32_t row_offset, void* stream) {
+    LLADA_CHECK_ARG(logits && out && n_rows > 0 && vocab > 0 && L > 0, "add_gumbel_noise: bad argument");
+    LLADA_CHECK_SUPPORTED(vocab % 8 == 0, "add_gumbel_noise: vocab=%d must be a multiple of 8", vocab);
+    const int64_t total = n_rows * (vocab / 8);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(gumbel_noise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, noise, temperature, out,
+                       n_rows, vocab, L, seed, step, row_offset);
+    LLADA_CHECK_LAUNCH("gumbel_noise_kernel");
+    return LLADA_OK;
+}
 
 extern "C" int llada_num_transfer_tokens(const int64_t* x, int32_t B, int32_t L, int32_t block_start,
                                          int32_t block_end, int64_t mask_id, int32_t steps, int32_t* sched,

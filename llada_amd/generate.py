@@ -20,12 +20,24 @@ EOS_ID = 126081   # generate.py:95,101
 EOT_ID = 126348   # generate.py:101
 
 
-def add_gumbel_noise(logits, temperature):
-    """generate.py:8-19 is fused into the remask kernel (float64 in registers); kept as a name
-    for callers that import it.  Temperature 0 returns the logits unchanged, as the reference."""
+def add_gumbel_noise(logits, temperature, *, noise=None, seed=0, step=0, row_offset=0):
+    """generate.py:8-19: temperature 0 returns ``logits`` itself; otherwise float64
+    ``exp(logits) / (-log u) ** temperature`` of the same shape [B, L, V].  ``noise`` (float64 uniforms, same
+    shape) replaces torch.rand_like; without it u comes from the library's Philox stream, with the counters
+    generate() uses for (seed, step, row_offset), so the arg-max of the result is that step's candidate token.
+    generate() itself ranks these scores inside its fused epilogue and never materialises them."""
     if temperature == 0:
-        return logits
-    raise NotImplementedError("Gumbel noise is applied inside llada_remask_scores; call generate()")
+        return logits                                                                     # :14-15
+    lib = _lib.load()
+    assert logits.dim() == 3 and logits.is_cuda
+    B, L, V = logits.shape
+    lg = logits.to(torch.float64).contiguous()                                            # :16
+    nz = None if noise is None else noise.to(device=lg.device, dtype=torch.float64).contiguous()
+    assert nz is None or nz.shape == lg.shape
+    out = torch.empty_like(lg)
+    _lib.check(lib.llada_add_gumbel_noise(lg.data_ptr(), _lib.ptr(nz), float(temperature), out.data_ptr(), B * L, V, L,
+                                          seed, step, row_offset, _lib.stream_ptr()))
+    return out
 
 
 def get_num_transfer_tokens(mask_index, steps):

@@ -261,6 +261,27 @@ def test_remask_full_vocab_planted_rows(lib, remasking, flags):
 
 
 
+def test_add_gumbel_noise_helper(lib):
+    """llada_amd.generate.add_gumbel_noise (generate.py:8-19 as a stand-alone map): temperature 0 returns the
+    same object; with injected uniforms it equals the oracle's float64 formula; with the library's Philox stream
+    its arg-max is the candidate token llada_remask_scores picks for the same (seed, step, row_offset)."""
+    from llada_amd.generate import add_gumbel_noise
+    B, L, V = 2, 5, 512
+    lg = fake_model_logits(21, 0, (B, L, V))
+    t = dev(lg, torch.bfloat16).reshape(B, L, V)
+    assert add_gumbel_noise(t, 0) is t
+    u = np.random.Generator(np.random.PCG64(8)).random((B, L, V))
+    got = add_gumbel_noise(t, 0.7, noise=torch.from_numpy(u)).cpu().numpy()
+    want = osamp.add_gumbel_noise(lg, 0.7, u)
+    assert got.dtype == np.float64 and np.allclose(got, want, rtol=1e-12, atol=0.0)
+    seed, step, row_offset = 77, 3, 5
+    noisy = add_gumbel_noise(t, 0.7, seed=seed, step=step, row_offset=row_offset)
+    x = np.full((B, L), MASK_ID, dtype=np.int64)
+    x0, _ = remask(lib, lg.reshape(B * L, V), None, 0.0, x, L, "low_confidence", 0, 0.7, seed=seed, step=step,
+                   row_offset=row_offset)
+    assert np.array_equal(noisy.argmax(-1).cpu().numpy(), x0)
+
+
 def test_num_transfer_tokens(lib):
     B, L = 4, 50
     g = np.random.Generator(np.random.PCG64(6))
