@@ -271,19 +271,35 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
         }
         return;
     }
+    // Write-out.  A lane holds 16 pieces of 4 dimensions of ONE query row: stored from the registers, every wave
+    // instruction would put 8 bytes into each of 32 rows at a 2d-byte stride (64 partial cache lines, 16 times).
+    // The wave's 32 x 128 result goes through its own slice of the K/V buffers (now idle) instead and leaves as
+    // 16 bytes per lane, 16 lanes per row: every instruction stores four whole 256-byte head rows.
+    if constexpr (!SPLIT) {
     const float inv = 1.0f / l_tot;
-    if (q < n_q) {
-        bf16_t* op = out + ((size_t)b * n_q + q) * d + (size_t)h * HD + 4 * hg;
+    constexpr int OROW = HD * 2 + 16;                      // LDS row stride: 16-byte aligned, 2-way at worst on the 8-byte writes
+    static_assert(4 * 32 * OROW <= NBUF * BUF_BYTES, "the write-out slices must fit the K/V buffers");
+    __syncthreads();                                       // every wave has finished reading the last K/V tile
+    unsigned char* my = lds + wave * (32 * OROW);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+    for (int db = 0; db < 4; ++db) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u32x2 w;
-                w[0] = pack_bf16x2(o[db][4 * c] * inv, o[db][4 * c + 1] * inv);
-                w[1] = pack_bf16x2(o[db][4 * c + 2] * inv, o[db][4 * c + 3] * inv);
-                *(u32x2*)(op + db * 32 + 8 * c) = w;
-            }
+        for (int c = 0; c < 4; ++c) {
+            u32x2 w;
+            w[0] = pack_bf16x2(o[db][4 * c] * inv, o[db][4 * c + 1] * inv);
+            w[1] = pack_bf16x2(o[db][4 * c + 2] * inv, o[db][4 * c + 3] * inv);
+            *(u32x2*)(my + r * OROW + (db * 32 + 8 * c + 4 * hg) * 2) = w;
         }
+    }
+    // the slice is private to the wave: its own LDS writes are ordered before its own reads
+    const int orow = lane >> 4, ochunk = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = i * 4 + orow;
+        const u32x4 v = *(const u32x4*)(my + rl * OROW + ochunk * 16);
+        const int qo = q0 + rl;
+        if (qo < n_q) *(u32x4*)(out + ((size_t)b * n_q + qo) * d + (size_t)h * HD + ochunk * 8) = v;
+    }
     }
 }
 
