@@ -21,6 +21,9 @@ constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int ROW_BYTES = BK * 2;  // 128
 constexpr int EPI_PARTIAL = 100;   // internal: float32 partial tile of a split-K launch
+#ifndef LLADA_GEMM_W_NT_128
+#define LLADA_GEMM_W_NT_128 1
+#endif
 
 struct GemmParams {
     const bf16_t* A;
@@ -58,6 +61,12 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_uniform) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_uniform, 16, 0, 0);
+}
+
+// Non-temporal form (aux = 2) for weight rows that only one to three workgroups ever read (small-M GEMMs): the
+// line is not kept in the caches on its way in.
+__device__ __forceinline__ void glds16_nt(const bf16_t* src, unsigned char* lds_uniform) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_uniform, 16, 0, 2);
 }
 
 // The same for lanes 0-31 only (512 contiguous LDS bytes).  EXEC is all ones in these kernels; the
@@ -378,6 +387,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     // plus 8 half pieces (4 rows, lanes 0-31 of a second instruction issued with EXEC[63:32] = 0).
     constexpr bool two_a = A_GROUPS > 8;
     constexpr bool half_a = A_GROUPS == 12;
+    constexpr bool W_NT = LLADA_GEMM_W_NT_128 && MFR == 4;      // the 128-row tile only runs at small M
 
     int tm, tn;
     tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
@@ -422,8 +432,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     auto issue_b = [&](int h, int tt) {
         const size_t ks = (size_t)min(tt, nk - 1) * p.w_kstride;
         unsigned char* base = smem + (tt & 1) * STAGE + 2 * AH_BYTES + h * BH_BYTES;
-        glds16(b_src[h][0] + ks, base + wave * 1024);
-        glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
+        if constexpr (W_NT) {
+            glds16_nt(b_src[h][0] + ks, base + wave * 1024);
+            glds16_nt(b_src[h][1] + ks, base + (wave + 8) * 1024);
+        } else {
+            glds16(b_src[h][0] + ks, base + wave * 1024);
+            glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
+        }
     };
 
     const int fr = lane & 15, fq = lane >> 4;

@@ -73,12 +73,23 @@ class LLaDAModel:
             self._rope[L] = (torch.cos(ang).to(self.device).contiguous(), torch.sin(ang).to(self.device).contiguous())
         return self._rope[L]
 
+    def _scratch(self, attr, need):
+        """The cached scratch buffer `attr`, grown when too small.  The buffer outlives the call that allocated it
+        and is handed to kernels as a raw pointer, so the caching allocator is told about every stream it is
+        used on (a caller may switch streams between calls); the old buffer of a grow is released only to
+        streams that have been told the same."""
+        ws = getattr(self, attr)
+        stream = torch.cuda.current_stream(self.device)
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                ws.record_stream(stream)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            setattr(self, attr, ws)
+        ws.record_stream(stream)
+        return ws
+
     def _workspace(self, n_seq, L, n_rows):
-        need = self.lib.llada_forward_workspace_bytes(C.byref(self._c_cfg), n_seq, L, n_rows)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        return self._scratch("_ws", self.lib.llada_forward_workspace_bytes(C.byref(self._c_cfg), n_seq, L, n_rows))
 
     def kv_cache(self, n_seq, L):
         """Storage for the block-cached sampler: every layer's [Q | K | V] image of n_seq x L tokens."""
@@ -102,11 +113,7 @@ class LLaDAModel:
         cos, sin = self.rope_tables(seq_len)
         if out is None:
             out = torch.empty(n_seq * bl, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
-        need = self.lib.llada_forward_block_workspace_bytes(C.byref(self._c_cfg), n_seq, seq_len, bl)
-        if self._ws_block is None or self._ws_block.numel() < need:
-            self._ws_block = None
-            self._ws_block = torch.empty(need, dtype=torch.uint8, device=self.device)
-        ws = self._ws_block
+        ws = self._scratch("_ws_block", self.lib.llada_forward_block_workspace_bytes(C.byref(self._c_cfg), n_seq, seq_len, bl))
         _lib.check(self.lib.llada_forward_block(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
                                                 cos.data_ptr(), sin.data_ptr(), n_seq, seq_len, block_start, bl,
                                                 kv_cache.data_ptr(), 1 if update_cache else 0, out.data_ptr(),
