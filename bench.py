@@ -135,9 +135,13 @@ class _TimedWindowDone(Exception):
     pass
 
 
-def timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all, on_start=None, row_offset=0):
+def timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all, on_start=None, row_offset=0, attention_mask=None,
+                **sampler):
     """Runs generate() (steps == gen_length) and times steps W_ .. W_+K_ of it between two
-    barrier + synchronize pairs; returns seconds for the K_ steps."""
+    barrier + synchronize pairs; returns seconds for the K_ steps.  ``sampler``: temperature, cfg_scale,
+    remasking, seed of the call (default: temperature 0, no guidance, low_confidence)."""
+    kw = dict(temperature=0., cfg_scale=0., remasking="low_confidence")
+    kw.update(sampler)
     state = {"n": 0, "t0": None, "t1": None}
 
     def begin():
@@ -159,8 +163,8 @@ def timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all, on_start=None,
         begin()
     while state["t1"] is None:
         try:
-            generate(model, prompt, None, steps=G, gen_length=G, block_length=bl, temperature=0., cfg_scale=0.,
-                     remasking="low_confidence", row_offset=row_offset, step_callback=cb)
+            generate(model, prompt, attention_mask, steps=G, gen_length=G, block_length=bl, row_offset=row_offset,
+                     step_callback=cb, **kw)
         except _TimedWindowDone:
             pass
     return state["t1"] - state["t0"]
@@ -214,6 +218,47 @@ def epilogue_roofline(torch, lib, _lib, device, rows, V, mask_id):
             "rows_per_launch": rows, "bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 2), "traffic": traffic,
             "large_launch": {"rows_per_launch": 2048, "achieved": round(big_bytes / t_big / 1e9, 1),
                              "frac": round(big_bytes / t_big / 8e12, 4), "avg_launch_us": round(t_big * 1e6, 2)}}
+
+
+def other_configs(torch, generate, model, cfg, sync_all):
+    """The remaining BASELINE configurations on this one GPU, a few steps each (the headline `value` stays the
+    8-rows-per-GPU line): the 64-prompt batch on ONE GPU at the headline shape and at gen512/blk64 (the N = 1
+    points of the strong-scaling runs), guidance + Gumbel noise at gen1024/blk128, and the likelihood."""
+    from llada_amd import get_log_likelihood
+    out = {}
+    gen = torch.Generator().manual_seed(1234)
+    prompts = torch.randint(0, 126000, (64, 128), generator=gen, dtype=torch.long)
+
+    def mfma_util(B, L, rows_head, ms):
+        d, F, V, nl = cfg.d_model, cfg.mlp_hidden, cfg.vocab_size, cfg.n_layers
+        lin = nl * (4 * d * d + 3 * d * F) - (d * d + 3 * d * F)
+        fl = 2.0 * B * L * lin + 2.0 * rows_head * (d * d + 3 * d * F) + 2.0 * rows_head * d * V + B * L * 4.0 * L * d * nl
+        return round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+    for name, G, bl in (("batch64_gen256_blk32_one_gpu", 256, 32), ("batch64_gen512_blk64_one_gpu", 512, 64)):
+        t = timed_steps(generate, model, prompts, G, bl, 2, 6, sync_all)
+        ms = 1e3 * t / 6
+        out[name] = {"ms_per_step": round(ms, 3), "tokens_per_s": round(64 / (ms * 1e-3), 2),
+                     "mfma_util_whole_step": mfma_util(64, 128 + G, 64 * bl, ms),
+                     "workload": f"64 prompts x P=128 on ONE GPU, gen_length={G}, steps={G}, block_length={bl}, temperature 0"}
+    G, bl = 1024, 128
+    am = torch.ones(1, 128, dtype=torch.long)
+    t = timed_steps(generate, model, prompts[:1], G, bl, 2, 8, sync_all, attention_mask=am, temperature=0.7, cfg_scale=1.0, seed=99)
+    ms = 1e3 * t / 8
+    out["cfg1_T0.7_gen1024_blk128"] = {"ms_per_step": round(ms, 3), "tokens_per_s": round(1 / (ms * 1e-3), 2),
+                                       "mfma_util_whole_step": mfma_util(2, 128 + G, 2 * bl, ms),
+                                       "workload": "1 prompt x P=128, cfg_scale=1.0 (2 x 1152 tokens per forward), temperature 0.7 "
+                                                   "(library Philox noise), gen_length=1024, steps=1024, block_length=128"}
+    g2 = torch.Generator().manual_seed(4321)
+    p_ids = torch.randint(0, 126000, (256,), generator=g2, dtype=torch.long)
+    a_ids = torch.randint(0, 126000, (128,), generator=g2, dtype=torch.long)
+    get_log_likelihood(model, p_ids, a_ids, mc_num=128, batch_size=32, seed=7)
+    sync_all()
+    t0 = time.perf_counter()
+    val = get_log_likelihood(model, p_ids, a_ids, mc_num=128, batch_size=32, seed=7)
+    sync_all()
+    out["likelihood_mc128_bs32"] = {"ms_per_call": round(1e3 * (time.perf_counter() - t0), 2), "log_likelihood": round(val, 4),
+                                    "workload": "get_log_likelihood(): prompt 256 + answer 128 tokens, mc_num=128, batch_size=32, one GPU"}
+    return out
 
 
 def likelihood_bench(args, torch, dist, model, cfg, world, rank, device, backend):
@@ -468,6 +513,8 @@ def main():
                 t1c = whole_call(prompt[:1])
                 rec["block_cached"]["batch1_tokens_per_s"] = round(G / t1c, 1)
                 rec["block_cached"]["batch1_ms_per_step_mean"] = round(1e3 * t1c / steps_total, 3)
+        if world == 1 and not strong and B == 8 and (P, G, bl) == (128, 256, 32) and not args.no_latency:
+            rec["other_configs"] = other_configs(torch, generate, model, cfg, sync_all)
         if world == 1 and not args.no_cpu_baseline:      # the host baseline is reported at N = 1 only
             rec["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(rec), flush=True)
