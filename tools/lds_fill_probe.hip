@@ -5,7 +5,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -o lds_fill_probe tools/lds_fill_probe.hip && ./lds_fill_probe
 //
-// mode 0: every workgroup streams the SAME 3 MiB region over and over (an activation matrix, cache-resident)
+// mode 0: every workgroup streams the SAME 4 MiB region over and over (an activation matrix, cache-resident)
 // mode 1: every workgroup streams its OWN slice of a 2 GiB buffer (weights, HBM)
 // mode 2: alternate pieces of both (a GEMM K step: some shared rows, some private rows)
 // Each of the 8 waves keeps `depth` KiB pieces in flight (counted vmcnt).
@@ -28,9 +28,24 @@ __global__ void __launch_bounds__(512) fill_kernel(const unsigned char* __restri
     for (int i = 0; i < pieces; ++i) {
         const size_t p = (size_t)i * 8 + wave;
         const bool use_shared = mode == 0 || (mode == 2 && (i & 1));
-        const unsigned char* src = use_shared ? shared_src + (p * 1024) % shared_bytes : own + (p * 1024) % own_bytes;
+        const unsigned char* src = use_shared ? shared_src + ((p * 1024) & (shared_bytes - 1)) : own + ((p * 1024) & (own_bytes - 1));
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane * 16), (lds_ptr_t)(lds + ((i % DEPTH) * 8 + wave) * 1024), 16, 0, 0);
         if (i >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Waves per workgroup: the shared stream by LDS-DMA from 4, 8 or 16 waves of ONE workgroup per CU (4 KiB in flight each).
+template <int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64) waves_kernel(const unsigned char* __restrict__ src, size_t bytes, int pieces) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = 0; i < pieces; ++i) {
+        const size_t p = (size_t)i * NWAVES + wave;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((p * 1024) & (bytes - 1)) + lane * 16),
+                                         (lds_ptr_t)(lds + ((i % 4) * NWAVES + wave) * 1024), 16, 0, 0);
+        if (i >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -51,7 +66,7 @@ __global__ void __launch_bounds__(512) reg_kernel(const unsigned char* __restric
         for (int j = 0; j < 8; ++j) {
             const size_t p = (size_t)(i + j) * 8 + wave;
             const bool use_shared = mode == 0 || (mode == 2 && ((i + j) & 1));
-            const unsigned char* src = use_shared ? shared_src + (p * 1024) % shared_bytes : own + (p * 1024) % own_bytes;
+            const unsigned char* src = use_shared ? shared_src + ((p * 1024) & (shared_bytes - 1)) : own + ((p * 1024) & (own_bytes - 1));
             v[j] = __builtin_nontemporal_load((const u32x4*)(src + lane * 16));
         }
 #pragma unroll
@@ -93,7 +108,7 @@ float run(int grid, int mode, const unsigned char* shared_src, size_t shared_byt
 }
 
 int main() {
-    const size_t shared_bytes = 3u << 20;            // 384 x 4096 bf16
+    const size_t shared_bytes = 4u << 20;            // about one 384 x 4096 bf16 activation matrix; a power of two (masks, not modulo)
     const size_t own_total = 2ull << 30;             // far beyond the 256 MiB Infinity Cache
     unsigned char *shared_src, *own_src;
     CHECK(hipMalloc(&shared_src, shared_bytes));
@@ -114,6 +129,31 @@ int main() {
                    bytes / t8 / 1e6 / grid, bytes / t16 / 1e6 / grid);
             fflush(stdout);
         }
+    {
+        auto time_waves = [&](auto kernel, int nw) {
+            const size_t lds_bytes = (size_t)4 * nw * 1024;
+            const int pcs = 4096 / nw * 8 / 8;           // 4 MiB per workgroup whatever the wave count
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(kernel, dim3(256), dim3(nw * 64), lds_bytes, 0, shared_src, shared_bytes, pcs);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kernel, dim3(256), dim3(nw * 64), lds_bytes, 0, shared_src, shared_bytes, pcs);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= 5;
+            const double bytes = 256.0 * nw * pcs * 1024;
+            printf("waves per workgroup %2d (256 workgroups, shared stream): %6.2f TB/s (%5.1f GB/s per CU)\n", nw, bytes / ms / 1e9,
+                   bytes / ms / 1e6 / 256);
+        };
+        time_waves(waves_kernel<2>, 2);
+        time_waves(waves_kernel<4>, 4);
+        time_waves(waves_kernel<8>, 8);
+        time_waves(waves_kernel<16>, 16);
+    }
     unsigned int* sink;
     CHECK(hipMalloc(&sink, 4096));
     for (int mode = 0; mode < 3; ++mode)
