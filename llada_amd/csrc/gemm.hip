@@ -41,6 +41,8 @@ struct GemmParams {
     int splits;     // K is cut into `splits` equal ranges, one workgroup each per output tile
     int n_tiles;    // tiles_m * tiles_n
     int no_store;   // diagnostic: skip the epilogue stores (timing experiments only)
+    int plan_nfh;   // host only: 0 = choose in launch(); 1 / 2 = the planner's N tile (128 / 256 columns) ...
+    int plan_splits;  // ... and its split count
     int band_m;     // M tiles per band of the tile walk
     int remap;      // 1: XCD-aware block -> tile map
     // RMSNorm of the updated residual stream fused into the split-K second pass (EPI_RESIDUAL only):
@@ -113,20 +115,22 @@ __device__ __forceinline__ void tile_of_block(int bid, int nt, int tiles_m, int 
 // The caller guarantees that no DMA or LDS read of the main loop is outstanding (barrier).
 // MGP = m fragments staged per pass (0: as many as the idle pipeline stages hold); `split` = which
 // float32 slab a partial tile goes to.
-template <int MFR, int EPI, int MGP = 0>
-__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR][4], int m0, int n0, int wm, int wn,
+template <int MFR, int EPI, int MGP = 0, int NFH = 2>
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR][2 * NFH], int m0, int n0, int wm, int wn,
                                            int fr, int fq, unsigned char* smem, int wave, int lane, int split) {
     if (p.no_store == 1) return;
+    constexpr int WCOLS = 32 * NFH;                    // output columns (before SwiGLU) of one wave
+    constexpr int NF = 2 * NFH;                        // 16-column fragments per wave
     if constexpr (EPI == EPI_PARTIAL) {
         const int m_base = m0 + wm * MFR * 16 + fr;
-        const int n_base = n0 + wn * 64 + fq * 4;
+        const int n_base = n0 + wn * WCOLS + fq * 4;
         float* slab = p.slab + (size_t)split * p.M * p.N;
 #pragma unroll
         for (int mf = 0; mf < MFR; ++mf) {
             const int m = m_base + mf * 16;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
+            for (int nf = 0; nf < NF; ++nf) {
                 const int n = n_base + nf * 16;
                 if (n >= p.N) continue;
                 *(f32x4*)(slab + (size_t)m * p.N + n) = acc[mf][nf];
@@ -134,13 +138,13 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
         }
     } else {
         constexpr bool SWI = (EPI == LLADA_EPI_SWIGLU);
-        constexpr int OUTC = SWI ? 32 : 64;            // output columns of this wave
+        constexpr int OUTC = SWI ? WCOLS / 2 : WCOLS;  // output columns of this wave
         constexpr int ROWB = OUTC * 2 + 16;            // LDS row stride in bytes
         constexpr int MG = MGP ? MGP : ((MFR == 8) ? 4 : MFR);   // m fragments per pass (LDS budget)
         constexpr int LPR = OUTC * 2 / 16;             // lanes per output row in the write-out
         constexpr int RPI = 64 / LPR;                  // rows per write-out instruction
         unsigned char* my = smem + wave * (MG * 16 * ROWB);
-        const int out_n0 = SWI ? (n0 + wn * 64) / 2 : n0 + wn * 64;   // first output column of the wave
+        const int out_n0 = SWI ? (n0 + wn * WCOLS) / 2 : n0 + wn * WCOLS;   // first output column of the wave
         const int out_cols = SWI ? p.N / 2 : p.N;
         [[maybe_unused]] const bool rope = n0 < p.rope_cols;          // uniform per tile (rope_cols % 256 == 0)
         constexpr int NI = MG * 16 / RPI;              // write-out instructions per pass
@@ -160,7 +164,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                     resid[i] = *(const u32x4*)(p.R + (size_t)min(m, (int)p.M - 1) * p.ldr + n_ld);
                 }
             }
-            [[maybe_unused]] f32x4 rc[MG][2], rs[MG][2];
+            [[maybe_unused]] f32x4 rc[MG][NFH], rs[MG][NFH];
             if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
                 if (rope) {
 #pragma unroll
@@ -168,8 +172,9 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                         const int m = m0 + wm * MFR * 16 + (pass * MG + ml) * 16 + fr;
                         const int pos = min(m, (int)p.M - 1) % p.seq_len;
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const int j = (wn & 1) * 32 + pr * 16 + fq * 4;  // rotary frequency of element 0
+                        for (int pr = 0; pr < NFH; ++pr) {
+                            // rotary frequency of element 0: 32-column group of the packed 128-column head
+                            const int j = (((n0 + wn * WCOLS + pr * 32) & 127) >> 5) * 16 + fq * 4;
                             rc[ml][pr] = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
                             rs[ml][pr] = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
                         }
@@ -183,7 +188,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                 unsigned char* row = my + (ml * 16 + fr) * ROWB + fq * 8;
                 if constexpr (EPI == LLADA_EPI_PLAIN || EPI == LLADA_EPI_RESIDUAL) {
 #pragma unroll
-                    for (int nf = 0; nf < 4; ++nf) {
+                    for (int nf = 0; nf < NF; ++nf) {
                         u32x2 o;
                         o[0] = pack_bf16x2(acc[mf][nf][0], acc[mf][nf][1]);
                         o[1] = pack_bf16x2(acc[mf][nf][2], acc[mf][nf][3]);
@@ -193,7 +198,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                     // packed head layout: 16-column blocks 0-15 | 64-79 | 16-31 | 80-95 | ...: fragments
                     // (2pr, 2pr+1) are rotary partners.  Columns >= rope_cols (V) pass through.
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
+                    for (int pr = 0; pr < NFH; ++pr) {
                         const f32x4 x1 = acc[mf][2 * pr], x2 = acc[mf][2 * pr + 1];
                         f32x4 o1 = x1, o2 = x2;
                         if (rope) {
@@ -215,7 +220,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
                     }
                 } else {  // SWIGLU: fragments (2pr, 2pr+1) = (gate, up) of the same 16 hidden units
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
+                    for (int pr = 0; pr < NFH; ++pr) {
                         const f32x4 g = acc[mf][2 * pr], u = acc[mf][2 * pr + 1];
                         float o[4];
 #pragma unroll
@@ -365,17 +370,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
 // region is refilled only after the barrier that follows its last read.
 // The vmcnt counts assume every phase issues its region, so past the last K tile the phases keep
 // issuing loads (of tile nk-1, into regions nobody reads again).
-template <int MFR, int EPI>
+template <int MFR, int EPI, int NFH = 2>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = MFR * 32;
     constexpr int HA = MFR / 2;                 // m fragments per A half (per wave)
     constexpr int AH_ROWS = MFR * 16;           // rows of one A-half region (both wave rows)
     constexpr int AH_BYTES = AH_ROWS * ROW_BYTES;
-    constexpr int BH_BYTES = 128 * ROW_BYTES;   // 4 waves x 32 columns
+    constexpr int BNT = 128 * NFH;              // weight rows (output columns) of the tile: 256, or 128 for small M
+    constexpr int BH_COLS = 16 * NFH;           // columns of one wave in one B half
+    constexpr int BH_BYTES = 4 * BH_COLS * ROW_BYTES;   // 4 waves x 32 (16) columns
     constexpr int STAGE = 2 * AH_BYTES + 2 * BH_BYTES;
     constexpr int A_GROUPS = AH_ROWS / 8;       // 1-KiB DMA pieces per A-half region: 8, 12 or 16
-    constexpr int NB = 2;                       // pieces per wave per B-half region
+    constexpr int NB = NFH;                     // pieces per wave per B-half region
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -387,17 +394,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     // plus 8 half pieces (4 rows, lanes 0-31 of a second instruction issued with EXEC[63:32] = 0).
     constexpr bool two_a = A_GROUPS > 8;
     constexpr bool half_a = A_GROUPS == 12;
-    constexpr bool W_NT = LLADA_GEMM_W_NT_128 && MFR == 4;      // the 128-row tile only runs at small M
+    constexpr bool W_NT = LLADA_GEMM_W_NT_128 && (MFR == 4 || NFH == 1);   // the 128-row / 128-column tiles only run at small M
 
     int tm, tn;
     tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
     const int nk = p.K / BK / p.splits;                         // K tiles of this workgroup's range
     const size_t k_first = (size_t)(blockIdx.x / p.n_tiles) * nk * BK;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BNT;
 
     // ---- DMA sources: region-local row rho -> tile row; chunk pre-swizzled by the local row ----
     const bf16_t* a_src[2][2];
-    const bf16_t* b_src[2][2];
+    const bf16_t* b_src[2][NB];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -410,12 +417,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
                 const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
                 a_src[h][u] = p.A + (size_t)min(m0 + trow, p.M - 1) * p.lda + k_first + chunk * 8;
             }
-            {
+            if (u < NB) {
                 const int g = wave + 8 * u;
                 const int rho = g * 8 + (lane >> 3);
-                const int tcol = (rho >> 5) * 64 + h * 32 + (rho & 31);
+                const int tcol = (rho / BH_COLS) * (2 * BH_COLS) + h * BH_COLS + rho % BH_COLS;
                 const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-                b_src[h][u] = p.W + (size_t)tn * p.w_tile_stride + (size_t)(min(n0 + tcol, p.N - 1) - n0) * p.w_row_stride +
+                const int n = min(n0 + tcol, p.N - 1);          // weight row; 256-row blocks in the tile-major layout
+                b_src[h][u] = p.W + (size_t)(n >> 8) * p.w_tile_stride + (size_t)(n & 255) * p.w_row_stride +
                               (k_first / BK) * p.w_kstride + chunk * 8;
             }
         }
@@ -434,10 +442,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         unsigned char* base = smem + (tt & 1) * STAGE + 2 * AH_BYTES + h * BH_BYTES;
         if constexpr (W_NT) {
             glds16_nt(b_src[h][0] + ks, base + wave * 1024);
-            glds16_nt(b_src[h][1] + ks, base + (wave + 8) * 1024);
+            if constexpr (NB == 2) glds16_nt(b_src[h][1] + ks, base + (wave + 8) * 1024);
         } else {
             glds16(b_src[h][0] + ks, base + wave * 1024);
-            glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
+            if constexpr (NB == 2) glds16(b_src[h][1] + ks, base + (wave + 8) * 1024);
         }
     };
 
@@ -445,7 +453,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     const int swz = fr >> 1;
     const int c0 = ((0 + fq) ^ swz) * 16, c1 = ((4 + fq) ^ swz) * 16;
     const int a_off = (wm * (MFR * 8) + fr) * ROW_BYTES;
-    const int b_off = 2 * AH_BYTES + (wn * 32 + fr) * ROW_BYTES;
+    const int b_off = 2 * AH_BYTES + (wn * BH_COLS + fr) * ROW_BYTES;
 
     auto read_a = [&](bf16x8 (&r)[HA][2], int h, int tt) {
         const unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES + a_off;
@@ -455,31 +463,31 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
             r[mf][1] = *(const bf16x8*)(base + mf * 16 * ROW_BYTES + c1);
         }
     };
-    auto read_b = [&](bf16x8 (&r)[2][2], int h, int tt) {
+    auto read_b = [&](bf16x8 (&r)[NFH][2], int h, int tt) {
         const unsigned char* base = smem + (tt & 1) * STAGE + h * BH_BYTES + b_off;
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
+        for (int nf = 0; nf < NFH; ++nf) {
             r[nf][0] = *(const bf16x8*)(base + nf * 16 * ROW_BYTES + c0);
             r[nf][1] = *(const bf16x8*)(base + nf * 16 * ROW_BYTES + c1);
         }
     };
 
-    f32x4 acc[MFR][4];
+    f32x4 acc[MFR][2 * NFH];
 #pragma unroll
     for (int i = 0; i < MFR; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2 * NFH; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[2][2], int ha, int hb) {
+    auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[NFH][2], int ha, int hb) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int mf = 0; mf < HA; ++mf)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
-                    acc[ha * HA + mf][hb * 2 + nf] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a[mf][ks], acc[ha * HA + mf][hb * 2 + nf], 0, 0, 0);
+                for (int nf = 0; nf < NFH; ++nf)
+                    acc[ha * HA + mf][hb * NFH + nf] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a[mf][ks], acc[ha * HA + mf][hb * NFH + nf], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -513,7 +521,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         BARRIER();                              \
     } while (0)
 
-    bf16x8 X[HA][2], Y[HA][2], P[2][2], Q[2][2];
+    bf16x8 X[HA][2], Y[HA][2], P[NFH][2], Q[NFH][2];
 
     // ---- prologue: tiles 0 and 1 in flight, in the order B0 A0 A1 B1 ----
     issue_b(0, 0);
@@ -551,7 +559,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills must land before the LDS is released
 
     __syncthreads();  // all waves are done reading the last stage: the LDS is free
-    store_tile<MFR, EPI>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane, blockIdx.x / p.n_tiles);
+    store_tile<MFR, EPI, 0, NFH>(p, acc, m0, n0, wm, wn, fr, fq, smem, wave, lane, blockIdx.x / p.n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,11 +981,25 @@ int pick_splits(int nt, int nk_total, int64_t M, int N, bool pipelined_ok) {
     return best;
 }
 
-template <int MFR, int EPI>
+template <int MFR, int EPI, int NFH = 2>
 int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     constexpr int BM = MFR * 32;
-    constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
+    constexpr int lds = 2 * (BM + 128 * NFH) * ROW_BYTES;
     const int nk = q.K / BK / q.splits;
+    if constexpr (NFH == 1) {   // 128-column tile: the pipelined loop only (the caller checked nk >= 4 and even)
+        static OncePerDevice attr4_set;
+        if (attr4_set.first()) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI, 1>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+                return LLADA_ERR_HIP;
+            }
+        }
+        hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI, 1>), dim3(grid), dim3(NTHREADS), lds, stream, q);
+        LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
+        return LLADA_OK;
+    } else {
     if constexpr (MFR != 8) {  // the persistent form of the 256-row tile spills registers
         // The persistent form pays off where a workgroup gets several tiles and the write-out issues no
         // loads of its own (gate/up projection: 6 tiles per CU at M = 3072); elsewhere it is neutral or
@@ -1029,9 +1051,107 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
     LLADA_CHECK_LAUNCH("gemm_bf16_kernel");
     return LLADA_OK;
+    }
 }
 
 int g_no_store = 0;       // diagnostic hook
+int g_force_cols = 0;     // test hook: 128 / 256 forces the N tile, 0 = automatic
+
+// ---- launch plans for small M (one or two sequences) ---------------------------------------------------------
+// At M = 384 the 256-column tile gives 96-192 work items for 256 CUs, so the tile height, the tile width (the
+// pipelined loop also runs 128 columns wide) and the split count are chosen together from a cost model fitted to
+// measured launches of the four LLaDA-8B projections at M = 384 (weights cold): microseconds =
+// rounds * (8 + t_step * K steps) + second pass of a split (4 + slab bytes / 3 TB/s), with t_step per
+// (tile rows, tile columns).  Model against measurement: QKV 192 x 128 unsplit 49.6 (49.6), 128 x 256 unsplit 56.6
+// (58.1); attention output 192 x 128 in 4 ranges 30.8 (27.1); MLP output 192 x 256 in 8 ranges 50.4 (49.8).
+struct Plan {
+    int mfr, nfh, splits;
+};
+
+inline double small_m_step_us(int mfr, int nfh) {
+    if (nfh == 2) return mfr == 4 ? 0.76 : (mfr == 6 ? 0.90 : 1.20);
+    return mfr == 4 ? 0.50 : 0.65;
+}
+
+inline double plan_cost(int64_t M, int N, int nk_total, int mfr, int nfh, int S) {
+    const int bm = mfr * 32, bn = 128 * nfh;
+    const int64_t items = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * S;
+    double cost = (double)((items + 255) / 256) * (8.0 + small_m_step_us(mfr, nfh) * (nk_total / S));
+    if (S > 1) cost += 4.0 + (double)S * M * N * 4 / 3.0e6;
+    return cost;
+}
+
+// Joint choice for a launch the legacy plan (pick_mfr, then pick_splits) leaves under-filled; {0, 0, 0} = keep the
+// legacy plan (always at large M: its choices are tuned and do not move).
+inline Plan choose_small_m_plan(int64_t M, int N, int K, int legacy_mfr) {
+    const Plan keep = {0, 0, 0};
+    if (g_use_pipelined != 1 || g_force_splits > 0 || g_force_cols != 0 || K % BK) return keep;
+    const int nk_total = K / BK;
+    const int lbm = legacy_mfr * 32;
+    const int64_t legacy_tiles = ((M + lbm - 1) / lbm) * ((N + BN - 1) / BN);
+    if (legacy_tiles >= 192) return keep;                 // the regime in which pick_splits considers splitting
+    Plan best = keep;
+    double best_cost = 1e30;
+    for (int mfr : {4, 6})
+        for (int nfh : {2, 1}) {
+            if (nfh == 1 && N % 128) continue;
+            for (int S = 1; S <= 16; S *= 2) {
+                if (nk_total % S) continue;
+                const int nk = nk_total / S;
+                if (nk < 4 || (nk & 1)) continue;
+                if (S > 1 && (size_t)S * M * N * 4 > g_slab_bytes) break;
+                const double c = plan_cost(M, N, nk_total, mfr, nfh, S);
+                if (c < best_cost) {
+                    best_cost = c;
+                    best = Plan{mfr, nfh, S};
+                }
+            }
+        }
+    return best;
+}
+
+// Test hook path (llada_gemm_force_tile_cols): split count for the 128-column tile, 0 = not applicable.
+template <int MFR>
+int pick_narrow(int64_t M, int N, int nk_total) {
+    if (g_force_cols != 128 || N % 128 != 0) return 0;
+    int best = 0;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 16; S *= 2) {
+        if (g_force_splits > 0 && S != g_force_splits) continue;
+        if (nk_total % S) continue;
+        const int nk = nk_total / S;
+        if (nk < 4 || (nk & 1)) continue;
+        if (S > 1 && (size_t)S * M * N * 4 > g_slab_bytes) continue;
+        const double c = plan_cost(M, N, nk_total, MFR, 1, S);
+        if (c < best_cost) {
+            best_cost = c;
+            best = S;
+        }
+    }
+    return best;
+}
+
+template <int EPI>
+int finish_split(const GemmParams& q, hipStream_t stream) {
+    if constexpr (EPI == LLADA_EPI_RESIDUAL) {
+        if (q.norm_out && q.norm_w && q.N % 8 == 0 && q.N <= 256 * 8 * 4) {
+            const int rgrid = q.M < 8192 ? q.M : 8192;
+            if (q.N <= 256 * 8 * 2)
+                hipLaunchKernelGGL((splitk_reduce_norm_kernel<2>), dim3(rgrid), dim3(256), 0, stream, q);
+            else
+                hipLaunchKernelGGL((splitk_reduce_norm_kernel<4>), dim3(rgrid), dim3(256), 0, stream, q);
+            LLADA_CHECK_LAUNCH("splitk_reduce_norm_kernel");
+            if (q.norm_fused) *q.norm_fused = 1;
+            return LLADA_OK;
+        }
+    }
+    const int64_t items = (int64_t)q.M * q.N / 4;
+    const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(grid), dim3(256), 0, stream, q);
+    LLADA_CHECK_LAUNCH("splitk_reduce_kernel");
+    return LLADA_OK;
+}
+
 template <int MFR, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = MFR * 32;
@@ -1050,27 +1170,24 @@ int launch(const GemmParams& p, hipStream_t stream) {
         q.w_row_stride = p.K;
         q.w_kstride = BK;
     }
-    q.splits = pick_splits(q.n_tiles, nk_total, p.M, p.N, g_use_pipelined != 0);
+    q.splits = p.plan_nfh ? p.plan_splits : pick_splits(q.n_tiles, nk_total, p.M, p.N, g_use_pipelined != 0);
+    if constexpr (MFR != 8) {     // 128-column tiles: small M only (the 256-row tile never is)
+        const int narrow = p.plan_nfh ? (p.plan_nfh == 1 ? p.plan_splits : 0)
+                                      : (g_use_pipelined == 1 ? pick_narrow<MFR>(p.M, p.N, nk_total) : 0);
+        if (narrow > 0) {
+            q.tiles_n = p.N / 128;
+            q.n_tiles = q.tiles_m * q.tiles_n;
+            q.splits = narrow;
+            if (narrow == 1) return launch_main<MFR, EPI, 1>(q, q.n_tiles, stream);
+            const int rc = launch_main<MFR, EPI_PARTIAL, 1>(q, q.n_tiles * narrow, stream);
+            if (rc != LLADA_OK) return rc;
+            return finish_split<EPI>(q, stream);
+        }
+    }
     if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
     const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
     if (rc != LLADA_OK) return rc;
-    if constexpr (EPI == LLADA_EPI_RESIDUAL) {
-        if (q.norm_out && q.norm_w && q.N % 8 == 0 && q.N <= 256 * 8 * 4) {
-            const int rgrid = q.M < 8192 ? q.M : 8192;
-            if (q.N <= 256 * 8 * 2)
-                hipLaunchKernelGGL((splitk_reduce_norm_kernel<2>), dim3(rgrid), dim3(256), 0, stream, q);
-            else
-                hipLaunchKernelGGL((splitk_reduce_norm_kernel<4>), dim3(rgrid), dim3(256), 0, stream, q);
-            LLADA_CHECK_LAUNCH("splitk_reduce_norm_kernel");
-            if (q.norm_fused) *q.norm_fused = 1;
-            return LLADA_OK;
-        }
-    }
-    const int64_t items = (int64_t)p.M * p.N / 4;
-    const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(grid), dim3(256), 0, stream, q);
-    LLADA_CHECK_LAUNCH("splitk_reduce_kernel");
-    return LLADA_OK;
+    return finish_split<EPI>(q, stream);
 }
 
 // Pick the M tile (128 / 192 / 256 rows): estimated time = rounds of tiles over the 256 CUs x rows per
@@ -1116,6 +1233,7 @@ extern "C" void llada_gemm_force_tile_rows(int rows) { g_force_mfr = rows / 32; 
 extern "C" void llada_gemm_use_pipelined(int on) { g_use_pipelined = on; }
 extern "C" void llada_gemm_stream_grid(int n) { g_stream_grid = n > 0 ? (n & ~7) > 0 ? (n & ~7) : 8 : 256; }
 extern "C" void llada_gemm_force_splits(int splits) { g_force_splits = splits; }
+extern "C" void llada_gemm_force_tile_cols(int cols) { g_force_cols = cols; }
 extern "C" void llada_gemm_no_store(int on) { g_no_store = on; }
 static int g_w_tiled = 0;  // timing hook: address W as tile-major whatever the caller says (results are garbage)
 extern "C" void llada_gemm_assume_tiled(int on) { g_w_tiled = on; }
@@ -1215,8 +1333,16 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     if (w_tiled || (g_w_tiled && N % BN == 0)) p.w_row_stride = BK;
     g_slab_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
-    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
+    int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
     LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
+    if (!g_force_mfr) {
+        const Plan pl = choose_small_m_plan(M, N, K, mfr);
+        if (pl.mfr) {
+            mfr = pl.mfr;
+            p.plan_nfh = pl.nfh;
+            p.plan_splits = pl.splits;
+        }
+    }
     const bool prof = g_prof.epilogue == epilogue && g_prof.rows == M && g_prof.count < g_prof.capacity;
     if (prof) (void)hipEventRecord(g_prof.start[g_prof.count], s);
     const int rc = gemm_dispatch(p, epilogue, mfr, aux, ldr, rope_cos, rope_sin, seq_len, ldc, N, s);
@@ -1286,8 +1412,16 @@ extern "C" int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, vo
     if (w_tiled || (g_w_tiled && N % BN == 0)) p.w_row_stride = BK;
     g_slab_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = (hipStream_t)stream;
-    const int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
+    int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
     LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
+    if (!g_force_mfr) {
+        const Plan pl = choose_small_m_plan(M, N, K, mfr);
+        if (pl.mfr) {
+            mfr = pl.mfr;
+            p.plan_nfh = pl.nfh;
+            p.plan_splits = pl.splits;
+        }
+    }
     const int rc = dispatch_mfr<LLADA_EPI_RESIDUAL>(p, mfr, s);
     if (rc != LLADA_OK || fused) return rc;
     return llada_rmsnorm_bf16(X, norm_w, H, M, N, eps, nullptr, stream);

@@ -259,6 +259,7 @@ def run_gemm(n_iter, seed):
             N = 256 * int(g.integers(1, 6)) if tiled else 8 * int(g.integers(1, 161))
             epi = int(g.integers(0, 2))                      # PLAIN / RESIDUAL
             rows = int(g.choice([0, 128, 192, 256]))
+            cols = int(g.choice([0, 128, 256]))
             use_ws = bool(g.integers(0, 2))
             A = g.integers(-4, 5, size=(M, K)).astype(np.float32)
             W = g.integers(-2, 3, size=(N, K)).astype(np.float32)
@@ -274,7 +275,8 @@ def run_gemm(n_iter, seed):
             out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
             ws = torch.empty(lib.llada_gemm_workspace_bytes(M, N, K) + 16, dtype=torch.uint8, device="cuda") if use_ws else None
             lib.llada_gemm_force_tile_rows(rows)
-            desc = f"it {it}: M={M} N={N} K={K} epi={epi} rows={rows} ws={use_ws} tiled={tiled}"
+            lib.llada_gemm_force_tile_cols(cols)
+            desc = f"it {it}: M={M} N={N} K={K} epi={epi} rows={rows} cols={cols} ws={use_ws} tiled={tiled}"
             _lib.check(lib.llada_gemm_bf16(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, K, N,
                                            epi | (_lib.GEMM_W_TILED if tiled else 0), Rt.data_ptr() if epi == 1 else None,
                                            N if epi == 1 else 0, None, None, 0, _lib.ptr(ws), 0 if ws is None else ws.numel() - 16,
@@ -284,6 +286,7 @@ def run_gemm(n_iter, seed):
             assert np.array_equal(got, ref), (desc, int((got != ref).sum()))
     finally:
         lib.llada_gemm_force_tile_rows(0)
+        lib.llada_gemm_force_tile_cols(0)
     return n_iter
 
 

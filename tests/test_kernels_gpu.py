@@ -115,6 +115,52 @@ def test_gemm_pipelined_equals_simple(lib, tile_rows):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("splits", [1, 2])
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("tile_rows", [128, 192])
+def test_gemm_narrow_tile_equals_wide(lib, tile_rows, tiled, splits):
+    """The 128-column tile of the pipelined loop (used when the 256-column one would leave most CUs idle: one
+    sequence) accumulates every output in the same k order as the 256-column tile: bit-identical results on random
+    data for every epilogue, ragged M, row-major and tile-major weights, with and without split-K (the split count
+    is forced so that both tiles cut K the same way)."""
+    from llada_amd.weights import pack_gate_up, pack_qkv, tile_major
+    K = 1024
+    g = np.random.Generator(np.random.PCG64(77))
+    n_seq, L, H, F = 2, 175, 4, 768
+    M, d = n_seq * L, H * 128
+    A = bf(round_bf16(g.standard_normal((M, K), dtype=np.float32)))
+    Wp = bf(round_bf16(g.standard_normal((1024, K), dtype=np.float32) * 0.05))
+    R = bf(round_bf16(g.standard_normal((M, 1024), dtype=np.float32)))
+    Wq, Wk, Wv = (bf(round_bf16(g.standard_normal((d, K), dtype=np.float32) * 0.05)) for _ in range(3))
+    Wg, Wu = (bf(round_bf16(g.standard_normal((F, K), dtype=np.float32) * 0.05)) for _ in range(2))
+    cos, sin = omodel.rope_tables(L, 128, 500000.0)
+    ct, st = dev(cos), dev(sin)
+    qkv_w, gu_w = pack_qkv(Wq, Wk, Wv, H), pack_gate_up(Wg, Wu)
+    flag = 0
+    if tiled:
+        Wp, qkv_w, gu_w, flag = tile_major(Wp), tile_major(qkv_w), tile_major(gu_w), 0x100
+    ws = torch.empty(4 * M * 3 * d, dtype=torch.float32, device="cuda")
+
+    def run_all():
+        return (gemm(lib, A, Wp, epi=0 | flag, workspace=ws), gemm(lib, A, Wp, epi=1 | flag, R=R, workspace=ws),
+                gemm(lib, A, qkv_w, epi=2 | flag, cos=ct, sin=st, seq_len=L, workspace=ws),
+                gemm(lib, A, gu_w, epi=3 | flag, out_cols=F, workspace=ws))
+
+    lib.llada_gemm_force_tile_rows(tile_rows)
+    lib.llada_gemm_force_splits(splits)
+    try:
+        lib.llada_gemm_force_tile_cols(256)
+        wide = run_all()
+        lib.llada_gemm_force_tile_cols(128)
+        narrow = run_all()
+    finally:
+        lib.llada_gemm_force_tile_cols(0)
+        lib.llada_gemm_force_splits(0)
+        lib.llada_gemm_force_tile_rows(0)
+    for a, b in zip(wide, narrow):
+        assert not torch.isnan(a.float()).any() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("splits", [2, 4, 8])
 @pytest.mark.parametrize("tile_rows", [128, 192, 256])
 def test_gemm_splitk_exact_integers(lib, splits, tile_rows):
