@@ -43,6 +43,7 @@ struct GemmParams {
     int no_store;   // diagnostic: skip the epilogue stores (timing experiments only)
     int plan_nfh;   // host only: 0 = choose in launch(); 1 / 2 = the planner's N tile (128 / 256 columns) ...
     int plan_splits;  // ... and its split count
+    int plan_ng;    // host only: > 0 = the small-M loop (gemm_small_m.h) with 32 * plan_ng tile columns
     int band_m;     // M tiles per band of the tile walk
     int remap;      // 1: XCD-aware block -> tile map
     // RMSNorm of the updated residual stream fused into the split-K second pass (EPI_RESIDUAL only):
@@ -952,6 +953,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_norm_kernel(const GemmParam
     }
 }
 
+#include "gemm_small_m.h"
+
 int g_use_pipelined = 1;  // test hook: 0 forces the simple two-stage kernel, 2 the persistent stream kernel, 3 never it
 int g_stream_grid = 256;  // workgroups of the persistent kernel (one per CU)
 int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
@@ -1056,6 +1059,8 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
 
 int g_no_store = 0;       // diagnostic hook
 int g_force_cols = 0;     // test hook: 128 / 256 forces the N tile, 0 = automatic
+int g_force_small_m = 0;  // test hook: > 0 runs the loop of gemm_small_m.h with 32 * value tile columns (never chosen automatically:
+                          // inside a denoising step it is 1-2 % slower than the plans below, see the header)
 
 // ---- launch plans for small M (one or two sequences) ---------------------------------------------------------
 // At M = 384 the 256-column tile gives 96-192 work items for 256 CUs, so the tile height, the tile width (the
@@ -1066,6 +1071,7 @@ int g_force_cols = 0;     // test hook: 128 / 256 forces the N tile, 0 = automat
 // (58.1); attention output 192 x 128 in 4 ranges 30.8 (27.1); MLP output 192 x 256 in 8 ranges 50.4 (49.8).
 struct Plan {
     int mfr, nfh, splits;
+    int ng;   // > 0: the 192-row small-M loop with 32 * ng columns (mfr / nfh unused)
 };
 
 inline double small_m_step_us(int mfr, int nfh) {
@@ -1081,10 +1087,15 @@ inline double plan_cost(int64_t M, int N, int nk_total, int mfr, int nfh, int S)
     return cost;
 }
 
-// Joint choice for a launch the legacy plan (pick_mfr, then pick_splits) leaves under-filled; {0, 0, 0} = keep the
-// legacy plan (always at large M: its choices are tuned and do not move).
+// Joint choice for a launch the legacy plan (pick_mfr, then pick_splits) leaves under-filled; {0, 0, 0, 0} = keep
+// the legacy plan (always at large M: its choices are tuned and do not move).
 inline Plan choose_small_m_plan(int64_t M, int N, int K, int legacy_mfr) {
-    const Plan keep = {0, 0, 0};
+    const Plan keep = {0, 0, 0, 0};
+    if (g_force_small_m > 0) {
+        const int S = g_force_splits > 0 ? g_force_splits : 1;
+        const bool ok = K % BK == 0 && (K / BK) % S == 0 && (S == 1 || (size_t)S * M * N * 4 <= g_slab_bytes);
+        return ok ? Plan{0, 0, S, g_force_small_m} : keep;
+    }
     if (g_use_pipelined != 1 || g_force_splits > 0 || g_force_cols != 0 || K % BK) return keep;
     const int nk_total = K / BK;
     const int lbm = legacy_mfr * 32;
@@ -1103,7 +1114,7 @@ inline Plan choose_small_m_plan(int64_t M, int N, int K, int legacy_mfr) {
                 const double c = plan_cost(M, N, nk_total, mfr, nfh, S);
                 if (c < best_cost) {
                     best_cost = c;
-                    best = Plan{mfr, nfh, S};
+                    best = Plan{mfr, nfh, S, 0};
                 }
             }
         }
@@ -1152,6 +1163,59 @@ int finish_split(const GemmParams& q, hipStream_t stream) {
     return LLADA_OK;
 }
 
+inline void set_weight_strides(GemmParams& q, const GemmParams& p) {
+    q.w_tile_stride = (size_t)BN * p.K;
+    if (p.w_row_stride == BK) {   // tile-major weights (the entry point checked N % 256 == 0)
+        q.w_kstride = BN * BK;
+    } else {
+        q.w_row_stride = p.K;
+        q.w_kstride = BK;
+    }
+}
+
+template <int NG, int EPI>
+int launch_small_m_kernel(const GemmParams& q, int grid, hipStream_t stream) {
+    static OncePerDevice attr_set;
+    if (attr_set.first()) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_small_m_kernel<NG, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SmallM<NG>::LDS_BYTES + LLADA_SM_TRACE * 8192);
+        if (e != hipSuccess) {
+            llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+            return LLADA_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL((gemm_bf16_small_m_kernel<NG, EPI>), dim3(grid), dim3(NTHREADS), SmallM<NG>::LDS_BYTES + LLADA_SM_TRACE * 8192, stream, q);
+    LLADA_CHECK_LAUNCH("gemm_bf16_small_m_kernel");
+    return LLADA_OK;
+}
+
+template <int NG, int EPI>
+int launch_small_m(const GemmParams& p, hipStream_t stream) {
+    GemmParams q = p;
+    q.no_store = g_no_store;
+    q.tiles_m = (int)((p.M + SM_BM - 1) / SM_BM);
+    q.tiles_n = (p.N + 32 * NG - 1) / (32 * NG);
+    q.n_tiles = 8 * ((q.tiles_n + 7) / 8) * q.tiles_m;   // the block -> tile map deals column tiles to the 8 XCDs
+    q.splits = p.plan_splits;
+    set_weight_strides(q, p);
+    if (q.splits == 1) return launch_small_m_kernel<NG, EPI>(q, q.n_tiles, stream);
+    const int rc = launch_small_m_kernel<NG, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
+    if (rc != LLADA_OK) return rc;
+    return finish_split<EPI>(q, stream);
+}
+
+template <int EPI>
+int dispatch_small_m(const GemmParams& p, hipStream_t stream) {
+    switch (p.plan_ng) {
+        case 1: return launch_small_m<1, EPI>(p, stream);
+        case 2: return launch_small_m<2, EPI>(p, stream);
+        case 3: return launch_small_m<3, EPI>(p, stream);
+        case 4: return launch_small_m<4, EPI>(p, stream);
+        case 6: return launch_small_m<6, EPI>(p, stream);
+        default: llada_set_error("gemm: no small-M loop with %d columns", 32 * p.plan_ng); return LLADA_ERR_INVALID;
+    }
+}
+
 template <int MFR, int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int BM = MFR * 32;
@@ -1163,13 +1227,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     q.tiles_n = (p.N + BN - 1) / BN;
     q.n_tiles = q.tiles_m * q.tiles_n;
     const int nk_total = p.K / BK;
-    q.w_tile_stride = (size_t)BN * p.K;
-    if (p.w_row_stride == BK) {   // tile-major weights (the entry point checked N % 256 == 0)
-        q.w_kstride = BN * BK;
-    } else {
-        q.w_row_stride = p.K;
-        q.w_kstride = BK;
-    }
+    set_weight_strides(q, p);
     q.splits = p.plan_nfh ? p.plan_splits : pick_splits(q.n_tiles, nk_total, p.M, p.N, g_use_pipelined != 0);
     if constexpr (MFR != 8) {     // 128-column tiles: small M only (the 256-row tile never is)
         const int narrow = p.plan_nfh ? (p.plan_nfh == 1 ? p.plan_splits : 0)
@@ -1218,6 +1276,7 @@ int pick_mfr(int64_t M, int N, int K) {
 
 template <int EPI>
 int dispatch_mfr(const GemmParams& p, int mfr, hipStream_t stream) {
+    if (p.plan_ng) return dispatch_small_m<EPI>(p, stream);
     switch (mfr) {
         case 8: return launch<8, EPI>(p, stream);
         case 6: return launch<6, EPI>(p, stream);
@@ -1235,6 +1294,7 @@ extern "C" void llada_gemm_stream_grid(int n) { g_stream_grid = n > 0 ? (n & ~7)
 extern "C" void llada_gemm_force_splits(int splits) { g_force_splits = splits; }
 extern "C" void llada_gemm_force_tile_cols(int cols) { g_force_cols = cols; }
 extern "C" void llada_gemm_no_store(int on) { g_no_store = on; }
+extern "C" void llada_gemm_force_small_m(int ng) { g_force_small_m = ng; }
 static int g_w_tiled = 0;  // timing hook: address W as tile-major whatever the caller says (results are garbage)
 extern "C" void llada_gemm_assume_tiled(int on) { g_w_tiled = on; }
 
@@ -1337,7 +1397,10 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
     if (!g_force_mfr) {
         const Plan pl = choose_small_m_plan(M, N, K, mfr);
-        if (pl.mfr) {
+        if (pl.ng) {
+            p.plan_ng = pl.ng;
+            p.plan_splits = pl.splits;
+        } else if (pl.mfr) {
             mfr = pl.mfr;
             p.plan_nfh = pl.nfh;
             p.plan_splits = pl.splits;
@@ -1416,7 +1479,10 @@ extern "C" int llada_gemm_residual_rmsnorm_bf16(const void* A, const void* W, vo
     LLADA_CHECK_ARG(mfr == 8 || mfr == 6 || mfr == 4, "gemm: forced tile rows must be 128, 192 or 256");
     if (!g_force_mfr) {
         const Plan pl = choose_small_m_plan(M, N, K, mfr);
-        if (pl.mfr) {
+        if (pl.ng) {
+            p.plan_ng = pl.ng;
+            p.plan_splits = pl.splits;
+        } else if (pl.mfr) {
             mfr = pl.mfr;
             p.plan_nfh = pl.nfh;
             p.plan_splits = pl.splits;

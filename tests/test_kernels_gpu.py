@@ -161,6 +161,56 @@ def test_gemm_narrow_tile_equals_wide(lib, tile_rows, tiled, splits):
         assert not torch.isnan(a.float()).any() and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("splits", [1, 2])
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("ng", [1, 2, 3, 4, 6])
+def test_gemm_small_m_loop_exact_integers(lib, ng, tiled, splits):
+    """The loop for one or two sequences (192 x 32*ng tiles, the two K halves of a step on different waves) adds in
+    another order than the main kernels, so it is compared on small integers, where every order is exact: all
+    four epilogues bit-identical to the 192 x 256 tile, ragged M, column tiles that overhang N and (ng = 3) that
+    straddle the rotary / pass-through boundary, row-major and tile-major weights, with and without split-K."""
+    from llada_amd.weights import pack_gate_up, pack_qkv, tile_major
+    K = 1024
+    g = np.random.Generator(np.random.PCG64(78))
+    n_seq, L, H, F = 2, 175, 4, 768
+    M, d = n_seq * L, H * 128
+    ints = lambda *shape: bf(g.integers(-3, 4, size=shape).astype(np.float32))
+    A, Wp = ints(M, K), ints(1024, K)
+    R = bf(round_bf16(g.standard_normal((M, 1024), dtype=np.float32) * 10))
+    Wq, Wk, Wv = (ints(d, K) for _ in range(3))
+    Wg, Wu = (bf(g.integers(-1, 2, size=(F, K)).astype(np.float32) * 0.03125) for _ in range(2))
+    cos, sin = omodel.rope_tables(L, 128, 500000.0)
+    ct, st = dev(cos), dev(sin)
+    qkv_w, gu_w = pack_qkv(Wq, Wk, Wv, H), pack_gate_up(Wg, Wu)
+    flag = 0
+    if tiled:
+        Wp, qkv_w, gu_w, flag = tile_major(Wp), tile_major(qkv_w), tile_major(gu_w), 0x100
+    ws = torch.empty(4 * M * 3 * d, dtype=torch.float32, device="cuda")
+
+    def run_all():
+        return (gemm(lib, A, Wp, epi=0 | flag, workspace=ws), gemm(lib, A, Wp, epi=1 | flag, R=R, workspace=ws),
+                gemm(lib, A, qkv_w, epi=2 | flag, cos=ct, sin=st, seq_len=L, workspace=ws),
+                gemm(lib, A, gu_w, epi=3 | flag, out_cols=F, workspace=ws))
+
+    lib.llada_gemm_force_splits(splits)
+    try:
+        lib.llada_gemm_force_tile_rows(192)
+        lib.llada_gemm_force_tile_cols(256)
+        wide = run_all()
+        lib.llada_gemm_force_tile_rows(0)
+        lib.llada_gemm_force_tile_cols(0)
+        lib.llada_gemm_force_small_m(ng)
+        small = run_all()
+    finally:
+        lib.llada_gemm_force_small_m(0)
+        lib.llada_gemm_force_tile_cols(0)
+        lib.llada_gemm_force_splits(0)
+        lib.llada_gemm_force_tile_rows(0)
+    for i, (a, b) in enumerate(zip(wide, small)):
+        assert not torch.isnan(a.float()).any() and a.float().abs().max() > 0
+        assert torch.equal(a, b), f"epilogue {i}: {(a.float() - b.float()).abs().max().item()}"
+
+
 @pytest.mark.parametrize("splits", [2, 4, 8])
 @pytest.mark.parametrize("tile_rows", [128, 192, 256])
 def test_gemm_splitk_exact_integers(lib, splits, tile_rows):

@@ -1,5 +1,6 @@
 """The four projections of one LLaDA-8B layer at M = 384 (one sequence): time per launch with the automatic plan,
-with the 256-column tile forced and with the 128-column tile forced (cold weights: a ring of layers)."""
+with the 256-column tile forced, with the 128-column tile forced and with the small-M loop at every tile width
+(cold weights: a ring of layers; second argument 1 = one copy, hot)."""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -44,4 +45,11 @@ for name, (N, K, epi) in shapes.items():
                 line += f"  S={splits}: {timed():6.1f}"
             print(line, flush=True)
     lib.llada_gemm_force_tile_rows(0); lib.llada_gemm_force_tile_cols(0); lib.llada_gemm_force_splits(0)
+    for ng in (1, 2, 3, 4, 6):
+        line = f"   small-M loop, 192 x {32 * ng:3d}:"
+        for splits in (1, 2, 4, 8):
+            lib.llada_gemm_force_small_m(ng); lib.llada_gemm_force_splits(splits)
+            line += f"  S={splits}: {timed():6.1f}"
+        print(line, flush=True)
+    lib.llada_gemm_force_small_m(0); lib.llada_gemm_force_splits(0)
     del Ws

@@ -8,6 +8,8 @@
 // mode 0: every workgroup streams the SAME 4 MiB region over and over (an activation matrix, cache-resident)
 // mode 1: every workgroup streams its OWN slice of a 2 GiB buffer (weights, HBM)
 // mode 2: alternate pieces of both (a GEMM K step: some shared rows, some private rows)
+// mode 3: waves 0-3 stream the shared region, waves 4-7 their own slice (the two streams never share a wave)
+// mode 4: waves 0-4 shared, waves 5-7 own (5 : 3, about the mix of a 192 x 96 tile)
 // Each of the 8 waves keeps `depth` KiB pieces in flight (counted vmcnt).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -27,7 +29,7 @@ __global__ void __launch_bounds__(512) fill_kernel(const unsigned char* __restri
     // wave w moves pieces w, w + 8, ...; piece p of a stream = 1 KiB at offset p KiB (wrapping)
     for (int i = 0; i < pieces; ++i) {
         const size_t p = (size_t)i * 8 + wave;
-        const bool use_shared = mode == 0 || (mode == 2 && (i & 1));
+        const bool use_shared = mode == 0 || (mode == 2 && (i & 1)) || (mode == 3 && wave < 4) || (mode == 4 && wave < 5);
         const unsigned char* src = use_shared ? shared_src + ((p * 1024) & (shared_bytes - 1)) : own + ((p * 1024) & (own_bytes - 1));
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane * 16), (lds_ptr_t)(lds + ((i % DEPTH) * 8 + wave) * 1024), 16, 0, 0);
         if (i >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
@@ -116,8 +118,8 @@ int main() {
     CHECK(hipMemset(shared_src, 1, shared_bytes));
     CHECK(hipMemset(own_src, 2, own_total));
     const int pieces = 512;                          // per wave: 512 KiB, 4 MiB per workgroup
-    const char* names[3] = {"shared (cache-resident)", "own slice (HBM)", "alternating"};
-    for (int mode = 0; mode < 3; ++mode)
+    const char* names[5] = {"shared (cache-resident)", "own slice (HBM)", "alternating", "split by wave 4:4", "split by wave 5:3"};
+    for (int mode = 0; mode < 5; ++mode)
         for (int grid : {64, 128, 192, 256, 512}) {
             const size_t own_bytes = own_total / 512;   // 4 MiB slices
             const double bytes = (double)grid * 8 * pieces * 1024;
