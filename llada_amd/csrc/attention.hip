@@ -185,13 +185,27 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+        // The K fragments are read two steps ahead of the MFMAs that use them (three register sets, order pinned
+        // with scheduling groups): left to itself the compiler reuses one set and every pair of MFMAs waits out a
+        // full LDS round trip.
+        bf16x8 kf[3][2];
+        auto read_k = [&](int ds) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                kf[ds % 3][kb] = *(const bf16x8*)(k_lds + kb * 32 * 256 + k_row_off + ((ds * 32) ^ k_xor));
+        };
+        read_k(0);
+        read_k(1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
         for (int ds = 0; ds < 8; ++ds) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *(const bf16x8*)(k_lds + kb * 32 * 256 + k_row_off + ((ds * 32) ^ k_xor));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+            if (ds + 2 < 8) {
+                read_k(ds + 2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds % 3][kb], qf[ds], s[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
         // The additive key bias is 0 or -inf, so it can be added before the scaling; the scale and the
         // running max are then folded into one FMA per score: p = 2^(s * scale - m).
