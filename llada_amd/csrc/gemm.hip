@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
 // region is refilled only after the barrier that follows its last read.
 // The vmcnt counts assume every phase issues its region, so past the last K tile the phases keep
 // issuing loads (of tile nk-1, into regions nobody reads again).
-template <int MFR, int EPI, int NFH = 2>
+template <int MFR, int EPI, int NFH = 2, int WNT = -1>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = MFR * 32;
@@ -395,7 +395,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     // plus 8 half pieces (4 rows, lanes 0-31 of a second instruction issued with EXEC[63:32] = 0).
     constexpr bool two_a = A_GROUPS > 8;
     constexpr bool half_a = A_GROUPS == 12;
-    constexpr bool W_NT = LLADA_GEMM_W_NT_128 && (MFR == 4 || NFH == 1);   // the 128-row / 128-column tiles only run at small M
+    // Non-temporal weight DMA where every weight line is read by one to three workgroups (small M): the 128-row and
+    // 128-column tiles only run there; the host asks for it explicitly (WNT = 1) when it plans a small-M launch on
+    // the 192 x 256 tile.  An HBM stream by LDS-DMA reads 6.9-7.0 TB/s with it against 5.9 TB/s without.
+    constexpr bool W_NT = WNT < 0 ? (LLADA_GEMM_W_NT_128 && (MFR == 4 || NFH == 1)) : (WNT != 0);
 
     int tm, tn;
     tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
@@ -984,7 +987,7 @@ int pick_splits(int nt, int nk_total, int64_t M, int N, bool pipelined_ok) {
     return best;
 }
 
-template <int MFR, int EPI, int NFH = 2>
+template <int MFR, int EPI, int NFH = 2, int WNT = -1>
 int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     constexpr int BM = MFR * 32;
     constexpr int lds = 2 * (BM + 128 * NFH) * ROW_BYTES;
@@ -1030,14 +1033,14 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
         if (g_use_pipelined && nk >= 4 && (nk & 1) == 0) {
             static OncePerDevice attr2_set;
             if (attr2_set.first()) {
-                hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI>,
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI, 2, WNT>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) {
                     llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
                     return LLADA_ERR_HIP;
                 }
             }
-            hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
+            hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI, 2, WNT>), dim3(grid), dim3(NTHREADS), lds, stream, q);
             LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
             return LLADA_OK;
         }
@@ -1100,7 +1103,12 @@ inline Plan choose_small_m_plan(int64_t M, int N, int K, int legacy_mfr) {
     const int nk_total = K / BK;
     const int lbm = legacy_mfr * 32;
     const int64_t legacy_tiles = ((M + lbm - 1) / lbm) * ((N + BN - 1) / BN);
-    if (legacy_tiles >= 192) return keep;                 // the regime in which pick_splits considers splitting
+    if (legacy_tiles >= 192) {                            // pick_splits would not split: the legacy plan stands ...
+        // ... but one round of 192-row tiles over at most three tile rows (gate/up at M = 384) still streams every
+        // weight line once or twice: same tile, unsplit, planned, i.e. with the non-temporal weight DMA
+        if (legacy_tiles <= 256 && legacy_mfr == 6 && M <= 3 * 192) return Plan{6, 2, 1, 0};
+        return keep;
+    }
     Plan best = keep;
     double best_cost = 1e30;
     for (int mfr : {4, 6})
@@ -1238,6 +1246,14 @@ int launch(const GemmParams& p, hipStream_t stream) {
             q.splits = narrow;
             if (narrow == 1) return launch_main<MFR, EPI, 1>(q, q.n_tiles, stream);
             const int rc = launch_main<MFR, EPI_PARTIAL, 1>(q, q.n_tiles * narrow, stream);
+            if (rc != LLADA_OK) return rc;
+            return finish_split<EPI>(q, stream);
+        }
+    }
+    if constexpr (MFR == 6) {     // a planned small-M launch on the 192 x 256 tile: the same loop, weights non-temporal
+        if (p.plan_nfh == 2 && g_use_pipelined == 1 && p.M <= 3 * 192) {   // at most three workgroups read a weight line
+            if (q.splits == 1) return launch_main<MFR, EPI, 2, 1>(q, q.n_tiles, stream);
+            const int rc = launch_main<MFR, EPI_PARTIAL, 2, 1>(q, q.n_tiles * q.splits, stream);
             if (rc != LLADA_OK) return rc;
             return finish_split<EPI>(q, stream);
         }

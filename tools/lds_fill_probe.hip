@@ -18,7 +18,7 @@
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int DEPTH>
+template <int DEPTH, int AUX = 0>
 __global__ void __launch_bounds__(512) fill_kernel(const unsigned char* __restrict__ shared_src, size_t shared_bytes,
                                                    const unsigned char* __restrict__ own_src, size_t own_bytes, int pieces,
                                                    int mode) {
@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(512) fill_kernel(const unsigned char* __restri
         const size_t p = (size_t)i * 8 + wave;
         const bool use_shared = mode == 0 || (mode == 2 && (i & 1)) || (mode == 3 && wave < 4) || (mode == 4 && wave < 5);
         const unsigned char* src = use_shared ? shared_src + ((p * 1024) & (shared_bytes - 1)) : own + ((p * 1024) & (own_bytes - 1));
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane * 16), (lds_ptr_t)(lds + ((i % DEPTH) * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane * 16), (lds_ptr_t)(lds + ((i % DEPTH) * 8 + wave) * 1024), 16, 0, AUX);
         if (i >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -86,21 +86,21 @@ __global__ void __launch_bounds__(512) reg_kernel(const unsigned char* __restric
         }                                                                         \
     } while (0)
 
-template <int DEPTH>
+template <int DEPTH, int AUX = 0>
 float run(int grid, int mode, const unsigned char* shared_src, size_t shared_bytes, const unsigned char* own_src,
           size_t own_bytes, int pieces) {
     const size_t lds_bytes = (size_t)DEPTH * 8 * 1024;
-    CHECK(hipFuncSetAttribute((const void*)fill_kernel<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    CHECK(hipFuncSetAttribute((const void*)(fill_kernel<DEPTH, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(fill_kernel<DEPTH>, dim3(grid), dim3(512), lds_bytes, 0, shared_src, shared_bytes, own_src, own_bytes,
+    hipLaunchKernelGGL((fill_kernel<DEPTH, AUX>), dim3(grid), dim3(512), lds_bytes, 0, shared_src, shared_bytes, own_src, own_bytes,
                        pieces, mode);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
     const int reps = 5;
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(fill_kernel<DEPTH>, dim3(grid), dim3(512), lds_bytes, 0, shared_src, shared_bytes, own_src,
+        hipLaunchKernelGGL((fill_kernel<DEPTH, AUX>), dim3(grid), dim3(512), lds_bytes, 0, shared_src, shared_bytes, own_src,
                            own_bytes, pieces, mode);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
@@ -131,6 +131,13 @@ int main() {
                    bytes / t8 / 1e6 / grid, bytes / t16 / 1e6 / grid);
             fflush(stdout);
         }
+    for (int grid : {128, 256, 512}) {   // the HBM stream with the non-temporal policy (aux = 2) on the DMA
+        const size_t own_bytes = own_total / 512;
+        const double bytes = (double)grid * 8 * pieces * 1024;
+        const float t8 = run<8, 2>(grid, 1, shared_src, shared_bytes, own_src, own_bytes, pieces);
+        const float t16 = run<16, 2>(grid, 1, shared_src, shared_bytes, own_src, own_bytes, pieces);
+        printf("own slice (HBM), nt DMA    grid %3d: depth 8/16 KiB per wave: %6.2f / %6.2f TB/s\n", grid, bytes / t8 / 1e9, bytes / t16 / 1e9);
+    }
     {
         auto time_waves = [&](auto kernel, int nw) {
             const size_t lds_bytes = (size_t)4 * nw * 1024;
