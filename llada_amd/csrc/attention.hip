@@ -25,6 +25,7 @@ namespace {
 constexpr int HD = 128;
 constexpr int KT = 64;          // keys per tile
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -40,6 +41,21 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
 // attn_combine_kernel.  Used when there are too few (query block, head, sequence) triples to fill the chip.
 // MODE 0: the whole key range; 1 = SPLIT; 2 = SPLIT with one tile per run (a single K/V buffer, so that four
 // one-wave workgroups fit in a CU's LDS).
+// Diagnostic build (-DLLADA_ATTN_TRACE=1): workgroup 0 of the unsplit kernel stamps five points of every key tile of every
+// wave with the shader clock (LDS) and copies them to the workspace the caller passes (tools/attn_trace.py).
+#ifndef LLADA_ATTN_TRACE
+#define LLADA_ATTN_TRACE 0
+#endif
+#if LLADA_ATTN_TRACE
+#define ATTN_STAMP(i)                                                                                  \
+    do {                                                                                               \
+        if (!SPLIT && blockIdx.x == 0 && t < 32 && lane == 0)                                          \
+            trace_lds[(wave * 32 + t) * 8 + (i)] = (unsigned)__builtin_readcyclecounter();             \
+    } while (0)
+#else
+#define ATTN_STAMP(i)
+#endif
+
 template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64, (NW >= 4 ? 2 : 1))
 attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, const bf16_t* __restrict__ kv_src,
@@ -53,6 +69,9 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
     constexpr int BUF_BYTES = 2 * TILE_BYTES;      // K then V
     __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF_BYTES + NBUF * KT * 4];
     float* bias_lds = (float*)(lds + NBUF * BUF_BYTES);
+#if LLADA_ATTN_TRACE
+    __shared__ unsigned trace_lds[NW * 32 * 8];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,8 +186,11 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
 
     for (int t = t_begin; t < n_tiles; ++t) {
         const int buf = (t - t_begin) & (NBUF - 1);
+        ATTN_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t (and Q) have landed
+        ATTN_STAMP(1);
         __syncthreads();                                    // ... everyone's; and tile t-1 is no longer read
+        ATTN_STAMP(2);
         if constexpr (NBUF == 2) {
             if (t + 1 < n_tiles) {
                 issue_tile((t + 1) * KT, buf ^ 1);
@@ -207,6 +229,7 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
             for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds % 3][kb], qf[ds], s[kb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
+        ATTN_STAMP(3);
         // The additive key bias is 0 or -inf, so it can be added before the scaling; the scale and the
         // running max are then folded into one FMA per score: p = 2^(s * scale - m).
         const bool need_bias = (key_mask != nullptr) || (kt0 + KT > L);
@@ -226,27 +249,40 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
-        float psum = 0.f;
+        // Lazy rescaling: the reference maximum of a row moves only when its running maximum has risen by more than
+        // 2^8 since the last move (any row of the wave: the branch is wave-uniform).  Until then the probabilities are
+        // taken against the older maximum and may reach 2^8, which float32 sums and bf16 operands hold as exactly as
+        // values below 1; the 64 multiplies of the output accumulators and the extra exponential are skipped on
+        // almost every tile after the first.
+        const float m_cand = fmaxf(m_run, mx);
+        if (__builtin_amdgcn_ballot_w64(m_cand > m_run + 8.0f) != 0) {
+            const float m_to = (m_cand == -INFINITY) ? 0.f : m_cand;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_to);
+            m_run = m_cand;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+        }
+        const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+        const f32x2 scale2 = {scale_log2e, scale_log2e}, negm2 = {-m_use, -m_use};
+        f32x2 psum2 = {0.f, 0.f};
         bf16x8 pb[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], scale_log2e, -m_use));
-                psum += pv;
-                pb[kb][e >> 3][e & 7] = (__bf16)pv;
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 t = __builtin_elementwise_fma((f32x2){s[kb][e], s[kb][e + 1]}, scale2, negm2);   // one packed FMA
+                const f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                psum2 += pv;
+                pb[kb][e >> 3][e & 7] = (__bf16)pv[0];
+                pb[kb][e >> 3][(e & 7) + 1] = (__bf16)pv[1];
             }
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+        l_run += psum2[0] + psum2[1];
 
+        ATTN_STAMP(4);
         // ---- O^T[dd][q] += V^T[dd][key] P^T[key][q] ----
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -264,7 +300,14 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
                 }
             }
         }
+        ATTN_STAMP(5);
     }
+#if LLADA_ATTN_TRACE
+    if (!SPLIT && blockIdx.x == 0 && part_o) {
+        __syncthreads();
+        for (int i = tid; i < NW * 32 * 8; i += NW * 64) ((unsigned*)part_o)[i] = trace_lds[i];
+    }
+#endif
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const int q = q0 + r;
@@ -373,7 +416,7 @@ void launch_attn(const bf16_t* q, int64_t q_stride, int n_q, const bf16_t* kv, i
     const int nqb = (n_q + NW * 32 - 1) / (NW * 32);
     dim3 grid(nqb * H * n_seq);
     hipLaunchKernelGGL((attn_bidir_kernel<NW, 0>), grid, dim3(NW * 64), 0, stream, q, q_stride, n_q, kv, kv_stride,
-                       key_mask, out, L, d, scale, 1, 0, (float*)nullptr, (float*)nullptr, n_rows, blk_kv, blk_start, blk_len,
+                       key_mask, out, L, d, scale, 1, 0, LLADA_ATTN_TRACE ? part_o : (float*)nullptr, (float*)nullptr, n_rows, blk_kv, blk_start, blk_len,
                        nqb, H);
 }
 
@@ -426,6 +469,7 @@ static int attn_dispatch(const bf16_t* qp, int64_t q_stride, int n_q, const bf16
             part_ml = part_o + (size_t)key_splits * n_rows * d;
         }
     }
+    if (LLADA_ATTN_TRACE && scratch && key_splits == 1) part_o = (float*)scratch;   // diagnostic build: the stamps go there
     LLADA_CHECK_SUPPORTED((int64_t)((n_q + nw * 32 - 1) / (nw * 32)) * n_heads * n_seq * key_splits < 0x7fffffffLL,
                           "attn: grid too large");
     switch (nw) {
