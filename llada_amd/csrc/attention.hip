@@ -18,6 +18,8 @@
 // source address and on the read address:
 //   K (ds_read_b128, lanes = 32 keys x 2 chunks):   16-byte chunk c of row k sits at c ^ (k & 15)
 //   V (ds_read_b64_tr_b16, lanes = 4 keys x 64 B):  64-byte slot s of row k sits at s ^ (k & 3)
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -191,10 +193,22 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
         ATTN_STAMP(1);
         __syncthreads();                                    // ... everyone's; and tile t-1 is no longer read
         ATTN_STAMP(2);
+        // The next tile's DMA: a wave stands still for ~50 cycles per 1-KiB piece while its instructions queue up in
+        // the CU's memory path (8 pieces: a quarter of the QK phase with the matrix pipe idle), so the four-wave kernel
+        // issues one piece behind each pair of QK MFMAs instead of all eight up front.
+        [[maybe_unused]] bool dma_in_loop = false;
+        [[maybe_unused]] size_t dma_adv = 0;
         if constexpr (NBUF == 2) {
             if (t + 1 < n_tiles) {
-                issue_tile((t + 1) * KT, buf ^ 1);
-                write_bias((t + 1) * KT, buf ^ 1);
+                const int kt1 = (t + 1) * KT;
+                write_bias(kt1, buf ^ 1);
+                if constexpr (NW == 4) {
+                    dma_in_loop = kt1 + KT <= L && (blk_base == nullptr || kt1 + KT <= blk_start || kt1 >= blk_start + blk_len);
+                    dma_adv = (size_t)kt1 * row_stride;
+                    if (!dma_in_loop) issue_tile(kt1, buf ^ 1);
+                } else {
+                    issue_tile(kt1, buf ^ 1);
+                }
             }
         }
         const unsigned char* k_lds = lds + buf * BUF_BYTES;
@@ -216,18 +230,34 @@ attn_bidir_kernel(const bf16_t* __restrict__ q_src, int64_t q_stride, int n_q, c
             for (int kb = 0; kb < 2; ++kb)
                 kf[ds % 3][kb] = *(const bf16x8*)(k_lds + kb * 32 * 256 + k_row_off + ((ds * 32) ^ k_xor));
         };
-        read_k(0);
-        read_k(1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        auto qk = [&](auto with_dma) {
+            read_k(0);
+            read_k(1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-        for (int ds = 0; ds < 8; ++ds) {
-            if (ds + 2 < 8) {
-                read_k(ds + 2);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            for (int ds = 0; ds < 8; ++ds) {
+                if (ds + 2 < 8) {
+                    read_k(ds + 2);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds % 3][kb], qf[ds], s[kb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if constexpr (decltype(with_dma)::value && NW == 4) {
+                    __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src0[ds] + dma_adv),
+                                                     (lds_void_ptr)(lds + (buf ^ 1) * BUF_BYTES + (wave + ds * NW) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
             }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds % 3][kb], qf[ds], s[kb], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        };
+        if constexpr (NW == 4) {
+            if (dma_in_loop)
+                qk(std::true_type{});
+            else
+                qk(std::false_type{});
+        } else {
+            qk(std::false_type{});
         }
         ATTN_STAMP(3);
         // The additive key bias is 0 or -inf, so it can be added before the scaling; the scale and the

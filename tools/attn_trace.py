@@ -13,6 +13,7 @@ st = torch.cuda.current_stream().cuda_stream
 qkv = torch.randn(B * L, 3 * d, device="cuda").to(torch.bfloat16)
 out = torch.zeros(B * L, d, device="cuda", dtype=torch.bfloat16)
 ws = torch.zeros(max(1 << 20, lib.llada_attn_workspace_bytes(B, L, L, H) // 4), dtype=torch.int32, device="cuda")
+lib.llada_attn_force_key_splits(1)      # the workspace only carries the stamps
 for _ in range(3):
     rc = lib.llada_attn_bidir_queries_bf16(qkv.data_ptr(), 3 * d, L, qkv.data_ptr(), None, out.data_ptr(), B, L, H, None, 0,
                                            ws.data_ptr(), ws.numel() * 4, st)
