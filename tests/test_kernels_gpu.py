@@ -490,6 +490,33 @@ def test_attention(lib, n_seq, L, H, masked, waves):
     assert err.max() <= 1.5e-2 * np.abs(ref).max(), err.max()
 
 
+def test_attention_left_padding_and_rising_scores(lib):
+    """A left-padded sequence whose first key tiles are masked completely (the running maximum stays -inf until the
+    first real key), and keys whose scores grow steadily along the sequence, so that a row's maximum rises in many
+    small steps (below the lazy-rescaling threshold of 2^8) and in a few large ones."""
+    n_seq, L, H = 2, 320, 2
+    d = H * 128
+    g = np.random.Generator(np.random.PCG64(11))
+    qkv = round_bf16(g.standard_normal((n_seq * L, 3 * d), dtype=np.float32))
+    ramp = np.linspace(0.25, 3.0, L, dtype=np.float32)
+    for b in range(n_seq):
+        qkv[b * L:(b + 1) * L, d:2 * d] *= ramp[:, None]
+    qkv[L + 300, d:2 * d] *= 8                 # one late, very large key in the padded sequence
+    qkv = round_bf16(qkv)
+    km = np.ones((n_seq, L), dtype=np.uint8)
+    km[1, :150] = 0                            # two whole 64-key tiles and part of a third
+    out = torch.full((n_seq * L, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    kmt, qt = dev(km), bf(qkv)
+    check(lib, lib.llada_attn_bidir_bf16(qt.data_ptr(), kmt.data_ptr(), out.data_ptr(), n_seq, L, H, stream()))
+    torch.cuda.synchronize()
+    x = qkv.reshape(n_seq, L, 3, H, 128)
+    q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    ref = omodel.attention(q, k, v, km, False).transpose(0, 2, 1, 3).reshape(n_seq * L, d)
+    assert np.isfinite(host(out)).all()
+    err = np.abs(host(out) - ref)
+    assert err.max() <= 1.5e-2 * np.abs(ref).max(), err.max()
+
+
 def test_attention_exact_uniform(lib):
     """All-equal scores: softmax is exactly uniform, so the output is the mean of V; with V
     holding small integers over a power-of-two number of keys the result is exact in bf16."""
