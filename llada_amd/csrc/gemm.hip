@@ -21,6 +21,11 @@ constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int ROW_BYTES = BK * 2;  // 128
 constexpr int EPI_PARTIAL = 100;   // internal: float32 partial tile of a split-K launch
+// Diagnostic builds (-DLLADA_GEMM_DEBUG=bits, results are garbage): the pipelined loop without 1 its DMA after the first
+// two K tiles, 2 its LDS fragment reads, 4 its MFMAs.
+#ifndef LLADA_GEMM_DEBUG
+#define LLADA_GEMM_DEBUG 0
+#endif
 #ifndef LLADA_GEMM_W_NT_128
 #define LLADA_GEMM_W_NT_128 1
 #endif
@@ -433,6 +438,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         }
 
     auto issue_a = [&](int h, int tt) {
+        if ((LLADA_GEMM_DEBUG & 1) && tt >= 2) return;
         const int ks = min(tt, nk - 1) * BK;
         unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES;
         glds16(a_src[h][0] + ks, base + wave * 1024);
@@ -442,6 +448,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
             glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
     };
     auto issue_b = [&](int h, int tt) {
+        if ((LLADA_GEMM_DEBUG & 1) && tt >= 2) return;
         const size_t ks = (size_t)min(tt, nk - 1) * p.w_kstride;
         unsigned char* base = smem + (tt & 1) * STAGE + 2 * AH_BYTES + h * BH_BYTES;
         if constexpr (W_NT) {
@@ -460,6 +467,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     const int b_off = 2 * AH_BYTES + (wn * BH_COLS + fr) * ROW_BYTES;
 
     auto read_a = [&](bf16x8 (&r)[HA][2], int h, int tt) {
+        if ((LLADA_GEMM_DEBUG & 2) && tt >= 2) return;
         const unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES + a_off;
 #pragma unroll
         for (int mf = 0; mf < HA; ++mf) {
@@ -468,6 +476,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         }
     };
     auto read_b = [&](bf16x8 (&r)[NFH][2], int h, int tt) {
+        if ((LLADA_GEMM_DEBUG & 2) && tt >= 2) return;
         const unsigned char* base = smem + (tt & 1) * STAGE + h * BH_BYTES + b_off;
 #pragma unroll
         for (int nf = 0; nf < NFH; ++nf) {
@@ -483,6 +492,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         for (int j = 0; j < 2 * NFH; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[NFH][2], int ha, int hb) {
+        if (LLADA_GEMM_DEBUG & 4) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
