@@ -22,7 +22,7 @@ constexpr int NTHREADS = 512;
 constexpr int ROW_BYTES = BK * 2;  // 128
 constexpr int EPI_PARTIAL = 100;   // internal: float32 partial tile of a split-K launch
 // Diagnostic builds (-DLLADA_GEMM_DEBUG=bits, results are garbage): the pipelined loop without 1 its DMA after the first
-// two K tiles, 2 its LDS fragment reads, 4 its MFMAs.
+// two K tiles, 2 its LDS fragment reads, 4 its MFMAs, 8 / 16 the DMA of the activation / weight rows only.
 #ifndef LLADA_GEMM_DEBUG
 #define LLADA_GEMM_DEBUG 0
 #endif
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
         }
 
     auto issue_a = [&](int h, int tt) {
-        if ((LLADA_GEMM_DEBUG & 1) && tt >= 2) return;
+        if ((LLADA_GEMM_DEBUG & (1 | 8)) && tt >= 2) return;
         const int ks = min(tt, nk - 1) * BK;
         unsigned char* base = smem + (tt & 1) * STAGE + h * AH_BYTES;
         glds16(a_src[h][0] + ks, base + wave * 1024);
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
             glds16(a_src[h][1] + ks, base + (wave + 8) * 1024);
     };
     auto issue_b = [&](int h, int tt) {
-        if ((LLADA_GEMM_DEBUG & 1) && tt >= 2) return;
+        if ((LLADA_GEMM_DEBUG & (1 | 16)) && tt >= 2) return;
         const size_t ks = (size_t)min(tt, nk - 1) * p.w_kstride;
         unsigned char* base = smem + (tt & 1) * STAGE + 2 * AH_BYTES + h * BH_BYTES;
         if constexpr (W_NT) {
