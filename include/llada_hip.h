@@ -113,7 +113,10 @@ size_t llada_forward_workspace_bytes(const llada_config* cfg, int32_t n_seq, int
 /* ids [n_seq, seq_len] int64; key_mask [n_seq, seq_len] uint8 (1 = attend) or NULL;
  * rope_cos / rope_sin [seq_len, 64] float32; logit_rows [n_logit_rows] int32 flat token
  * indices (seq * seq_len + pos) whose logits are wanted, or NULL for all tokens in order;
- * logits_out [n_logit_rows, vocab] bf16. */
+ * logits_out [n_logit_rows, vocab] bf16.
+ * On return (stream-ordered) the first n_seq * seq_len * d_model bf16 of `workspace` hold the residual stream
+ * after the last layer, before the final norm (a model's last `hidden_states`), provided every token's logits
+ * were asked for (logit_rows == NULL); with a row subset the last layer updates only those rows elsewhere. */
 int llada_forward(const llada_config* cfg, const llada_weights* w, const int64_t* ids, const uint8_t* key_mask,
                   const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
                   const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,

@@ -7,10 +7,11 @@ they can be switched over by changing an import:
                                            /root/reference/opencompass/opencompass/models/dllm.py:371-405
                                            and :503-549 (left-padded batch encode, no attention mask,
                                            decode of the last ``gen_length`` tokens, stop words).
-                                           The wrappers take inputs that are already in tokenizer form
-                                           (chat: a string or a list of {"role", "content"} messages per
-                                           request; base: a string per request); OpenCompass' PromptList
-                                           conversion (dllm.py:461-501) stays in OpenCompass.
+                                           Requests arrive as OpenCompass hands them over: a string, or a
+                                           PromptList of {"role": HUMAN | BOT | SYSTEM, "prompt": text} items,
+                                           turned into chat messages / one flat string as dllm.py:461-501 does
+                                           (``chat_messages`` / ``flat_prompt`` below); lists that are already
+                                           {"role", "content"} chat messages are accepted as well.
 
 Only the parts that touch the sampler are restated; the OpenCompass base class (mmengine registry,
 template parsers, perplexity helpers that the reference itself disables at dllm.py:423) is not.
@@ -61,6 +62,49 @@ def chat(model_path, device="cuda", input_fn=input, print_fn=print):
         print_fn('-----------------------------------------------------------------------')
 
 
+_OPENCOMPASS_ROLES = {"HUMAN": "user", "BOT": "assistant", "SYSTEM": "system"}
+
+
+def chat_messages(request, merge_role=True, skip_empty_prompt=True):
+    """One request -> the message list tokenizer.apply_chat_template takes (what dllm.py:461-488 builds per
+    input): a string is a single user turn; a PromptList item {"role": "HUMAN" | "BOT" | "SYSTEM", "prompt": text}
+    becomes {"role": "user" | "assistant" | "system", "content": text}; items with an empty prompt are dropped;
+    consecutive turns of one role are joined with a newline.  Items already in {"role", "content"} form pass
+    through (an extension).  Anything else raises with the offending item named."""
+    if isinstance(request, str):
+        return [{"role": "user", "content": request}]
+    turns = []
+    for item in request:
+        if not isinstance(item, dict) or "role" not in item or not ("prompt" in item or "content" in item):
+            raise TypeError(f"chat request item {item!r}: expected a dict with 'role' and 'prompt' (or 'content')")
+        if "prompt" in item:
+            if item["role"] not in _OPENCOMPASS_ROLES:
+                raise KeyError(item["role"])                     # the reference's role table raises the same
+            role, text = _OPENCOMPASS_ROLES[item["role"]], item["prompt"]
+            if skip_empty_prompt and not text:
+                continue
+        else:
+            role, text = item["role"], item["content"]
+        if merge_role and turns and turns[-1]["role"] == role:
+            turns[-1]["content"] += "\n" + text
+        else:
+            turns.append({"role": role, "content": text})
+    return turns
+
+
+def flat_prompt(request):
+    """One request -> the plain string a base model is prompted with (dllm.py:491-501): a string as it is, a
+    PromptList's texts concatenated without separators."""
+    if isinstance(request, str):
+        return request
+    parts = []
+    for item in request:
+        if not isinstance(item, dict) or not ("prompt" in item or "content" in item):
+            raise TypeError(f"base-model request item {item!r}: expected a dict with 'prompt'")
+        parts.append(item["prompt"] if "prompt" in item else item["content"])
+    return "".join(parts)
+
+
 class LLaDAModel:
     """The sampler-facing part of dllm.py:69-405 (chat-template model)."""
 
@@ -86,9 +130,9 @@ class LLaDAModel:
         return len(self.tokenizer.encode(prompt))                                          # dllm.py:360-369
 
     def _prompts(self, inputs):
-        """One chat-template prompt per request (dllm.py:375-377); a bare string is one user message."""
-        messages = [[{"role": "user", "content": m}] if isinstance(m, str) else list(m) for m in inputs]
-        return [self.tokenizer.apply_chat_template(m_i, add_generation_prompt=True, tokenize=False) for m_i in messages]
+        """One chat-template prompt per request (dllm.py:373-374)."""
+        return [self.tokenizer.apply_chat_template(chat_messages(m), add_generation_prompt=True, tokenize=False)
+                for m in inputs]
 
     def _sample(self, prompt_texts):
         self.tokenizer.padding_side = "left"                                               # dllm.py:380
@@ -117,9 +161,7 @@ class LLaDABaseModel(LLaDAModel):
     """dllm.py:503-554 (base model: plain concatenated prompt, stop-word trimming)."""
 
     def _prompts(self, inputs):
-        if not all(isinstance(m, str) for m in inputs):
-            raise TypeError("LLaDABaseModel takes one prompt string per request")
-        return list(inputs)
+        return [flat_prompt(m) for m in inputs]                                             # dllm.py:509-510
 
     def generate(self, inputs, max_out_len=None):
         responses = self._sample(self._prompts(inputs))
@@ -133,4 +175,4 @@ class LLaDABaseModel(LLaDAModel):
         return responses
 
     def get_token_len(self, prompt, add_special_tokens=True):
-        return len(self.tokenizer(prompt, add_special_tokens=add_special_tokens)['input_ids'])   # dllm.py:551-554
+        return len(self.tokenizer(flat_prompt(prompt), add_special_tokens=add_special_tokens)['input_ids'])   # dllm.py:551-554

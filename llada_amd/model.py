@@ -152,6 +152,29 @@ class LLaDAModel:
         _lib.check(rc)
         return out
 
+    def residual_stream(self, input_ids, attention_mask=None, n_layers=None):
+        """The residual stream [n_seq, L, d] (bf16) after the first ``n_layers`` blocks (default: all), before the
+        final norm -- the per-layer ``hidden_states`` of an HF model.  Runs the forward truncated to that depth and
+        copies the stream out of the workspace (llada_forward leaves it in the first n_seq * L * d elements)."""
+        ids = input_ids.to(self.device).contiguous()
+        n_seq, L = ids.shape
+        nl = self.cfg.n_layers if n_layers is None else int(n_layers)
+        assert 0 <= nl <= self.cfg.n_layers
+        c = self.cfg
+        cc = _lib.Config(c.d_model, nl, c.n_heads, c.mlp_hidden, c.vocab_size, c.rms_eps)
+        km = None
+        if attention_mask is not None:
+            km = (attention_mask.to(self.device) != 0).to(torch.uint8).contiguous()
+        cos, sin = self.rope_tables(L)
+        M = n_seq * L
+        # every row is asked for, so the last layer runs on all of them (no row pruning)
+        out = torch.empty(M, c.vocab_size, dtype=torch.bfloat16, device=self.device)
+        ws = self._scratch("_ws", self.lib.llada_forward_workspace_bytes(C.byref(cc), n_seq, L, M))
+        _lib.check(self.lib.llada_forward(C.byref(cc), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km), cos.data_ptr(),
+                                          sin.data_ptr(), n_seq, L, None, M, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _lib.stream_ptr()))
+        return ws[:n_seq * L * c.d_model * 2].view(torch.bfloat16).view(n_seq, L, c.d_model).clone()
+
     def __call__(self, input_ids, attention_mask=None):
         n_seq, L = input_ids.shape
         logits = self.forward_rows(input_ids, attention_mask, None)

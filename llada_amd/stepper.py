@@ -20,7 +20,7 @@ from .model import LLaDAModel, check_token_ids
 class GenerationStepper:
     def __init__(self, model, prompt, attention_mask=None, gen_length=128, block_length=32, temperature=0.,
                  cfg_scale=0., remasking='low_confidence', mask_id=126336, logits_eos_inf=False,
-                 confidence_eos_eot_inf=False, seed=0):
+                 confidence_eos_eot_inf=False, seed=0, max_history=None):
         assert gen_length % block_length == 0                                             # generate.py:68
         if remasking not in _lib.REMASK:
             raise NotImplementedError(remasking)                                          # :122-123
@@ -49,16 +49,47 @@ class GenerationStepper:
         self.ws = torch.empty(self.lib.llada_rows_workspace_bytes(B * self.L), dtype=torch.uint8, device=self.device)
         self.step_index = 0            # forwards run so far (the Philox step counter)
         self.scores_valid = False      # x0 / conf belong to the current x
-        self.history = {0: self.x.clone()}
+        # state after every select(): (tokens, Philox step counter), so that a replay after rewind() draws the
+        # noise the original run drew.  ``max_history``: keep only that many most recent states (None = all;
+        # each is a [B, L] int64 clone); state 0, the fully masked answer, is always kept.
+        self.max_history = max_history
+        self.history = {0: (self.x.clone(), 0)}
+        self._n_states = 1
+        self._block = None             # cached index of the current block; None = recompute (one host read)
 
     # -- state ------------------------------------------------------------------------------------------
     @property
     def block(self):
-        """Index of the first block that still holds a mask token (num_blocks when none does)."""
-        gen = self.x[:, self.P:].reshape(self.B, self.num_blocks, self.block_length)
-        open_blocks = (gen == self.mask_id).any(dim=2).any(dim=0)
-        idx = torch.nonzero(open_blocks)
-        return int(idx[0].item()) if idx.numel() else self.num_blocks
+        """Index of the first block that still holds a mask token (num_blocks when none does).  Computed once per
+        change of the tokens (one host read), then cached."""
+        if self._block is None:
+            gen = self.x[:, self.P:].reshape(self.B, self.num_blocks, self.block_length)
+            open_blocks = (gen == self.mask_id).any(dim=2).any(dim=0)
+            idx = torch.nonzero(open_blocks)
+            self._block = int(idx[0].item()) if idx.numel() else self.num_blocks
+        return self._block
+
+    def _force(self, manual_selections, drop_scores):
+        """Writes the caller's own tokens ({column: id} for row 0, or {(row, column): id}) into x.  Ids go through
+        the same vocabulary check as the prompt (the embedding kernel would clamp an out-of-range id silently)."""
+        if not manual_selections:
+            return
+        items = []
+        for key, tok in manual_selections.items():
+            r, c = key if isinstance(key, tuple) else (0, key)
+            if 0 <= c < self.L:
+                if not 0 <= r < self.B:
+                    raise IndexError(f"manual selection row {r} is outside the batch of {self.B}")
+                items.append((r, c, int(tok)))
+        if not items:
+            return
+        if self.fast:
+            check_token_ids(torch.tensor([t for _, _, t in items]), self.model.cfg.vocab_size, None, "manual_selections")
+        for r, c, tok in items:
+            self.x[r, c] = tok
+            if drop_scores:
+                self.conf[r, c] = float("-inf")            # no longer a candidate
+        self._block = None
 
     @property
     def done(self):
@@ -123,12 +154,7 @@ class GenerationStepper:
         row; never more than the row has mask tokens left in the block).  Returns the tokens [B, L]."""
         if not self.scores_valid:
             raise ValueError("no cached scores: run forward() first")
-        if manual_selections:
-            for key, tok in manual_selections.items():
-                r, c = key if isinstance(key, tuple) else (0, key)
-                if 0 <= c < self.L:
-                    self.x[r, c] = int(tok)
-                    self.conf[r, c] = float("-inf")        # no longer a candidate
+        self._force(manual_selections, True)
         left = (self.x == self.mask_id) & ~torch.isneginf(self.conf)      # candidates: finite or NaN scores (topk ranks NaN highest)
         k = torch.as_tensor(tokens_to_select, device=self.device).expand(self.B).to(torch.int64)
         k = torch.minimum(k, left.sum(dim=1)).to(torch.int32).reshape(self.B, 1).contiguous()
@@ -136,25 +162,33 @@ class GenerationStepper:
                                                 k.data_ptr(), 1, 0, _lib.stream_ptr()))
         # committed positions stop being candidates for a further select() on the same scores
         self.conf.masked_fill_(self.x != self.mask_id, float("-inf"))
-        self.history[len(self.history)] = self.x.clone()
+        self._block = None
+        self.history[self._n_states] = (self.x.clone(), self.step_index)
+        self._n_states += 1
+        if self.max_history is not None:
+            for s in sorted(k_ for k_ in self.history if k_ != 0)[:-self.max_history or None]:
+                del self.history[s]
         return self.x
 
     def step(self, tokens_to_select=1, manual_selections=None):
         """forward() + select(): one denoising step."""
-        if manual_selections:                       # forced tokens are part of the input of the forward
-            for key, tok in manual_selections.items():
-                r, c = key if isinstance(key, tuple) else (0, key)
-                if 0 <= c < self.L:
-                    self.x[r, c] = int(tok)
+        self._force(manual_selections, False)       # forced tokens are part of the input of the forward
         self.forward()
         return self.select(tokens_to_select)
 
     def rewind(self, state):
-        """Back to the tokens after the ``state``-th select() (0 = the initial, fully masked answer)."""
+        """Back to the tokens after the ``state``-th select() (0 = the initial, fully masked answer), and to the
+        random-stream position of that moment: stepping on from here with the same arguments repeats the original
+        run exactly, sampled noise included.  None if that state is unknown (never reached, or dropped by
+        ``max_history``)."""
         if state not in self.history:
             return None
-        self.x.copy_(self.history[state])
+        x, step_index = self.history[state]
+        self.x.copy_(x)
+        self.step_index = step_index
         for s in [s for s in self.history if s > state]:
             del self.history[s]
+        self._n_states = state + 1
         self.scores_valid = False
+        self._block = None
         return self.x

@@ -109,9 +109,17 @@ class LLaDAWeights:
         return self
 
     @classmethod
-    def random(cls, cfg, device, seed=0, std=0.02, head_scale=8.0, packed=True, tiled=None):
+    def random(cls, cfg, device, seed=0, std=0.02, head_scale=8.0, packed=True, tiled=None, resid_std=None, embed_std=None):
         """i.i.d. N(0, std^2) bf16 weights at the configured shapes, norm weights 1, LM-head rows
-        scaled by head_scale so logits are not degenerate.  Generated on the device."""
+        scaled by head_scale so logits are not degenerate.  Generated on the device.
+        ``resid_std``: standard deviation of the two matrices that write into the residual stream (attn_out,
+        ff_out); None = std.  ``std / sqrt(2 * n_layers)`` is the depth-scaled initialisation of trained
+        Llama / OLMo-style stacks: every layer then moves the stream by a small fraction of its size and a
+        rounding made in one layer is not amplified by the ones above it.  The generator stream is the same
+        for every value (the draw is scaled afterwards).  ``embed_std``: standard deviation of the embedding
+        table (None = std).  A pre-norm stack is invariant to the common scale of everything written into the
+        stream, so what conditions it is the RATIO embedding : layer update; embed_std >> resid_std * sqrt(width)
+        gives a stream every layer changes only slightly."""
         self = cls(cfg, device, packed, tiled)
         g = torch.Generator(device=self.device)
         g.manual_seed(seed)
@@ -120,19 +128,20 @@ class LLaDAWeights:
             return (torch.randn(n, k, generator=g, device=self.device, dtype=torch.float32) * s).to(torch.bfloat16)
 
         d, F, V = cfg.d_model, cfg.mlp_hidden, cfg.vocab_size
-        self.wte = w(V, d)
+        rs = std if resid_std is None else resid_std
+        self.wte = w(V, d, std if embed_std is None else embed_std)
         ones = torch.ones(d, device=self.device, dtype=torch.bfloat16)
         for _ in range(cfg.n_layers):
             self.attn_norm.append(ones.clone())
             q, k, v = w(d, d), w(d, d), w(d, d)
             self.wqkv.append(pack_qkv(q, k, v, cfg.n_heads) if packed else torch.cat([q, k, v]).contiguous())
             del q, k, v
-            self.wo.append(w(d, d))
+            self.wo.append(w(d, d, rs))
             self.ff_norm.append(ones.clone())
             gate, up = w(F, d), w(F, d)
             self.wgu.append(pack_gate_up(gate, up) if packed else torch.cat([gate, up]).contiguous())
             del gate, up
-            self.wdown.append(w(d, F))
+            self.wdown.append(w(d, F, rs))
         self.ln_f = ones.clone()
         self.lm_head = w(V, d, std * head_scale)
         return self._finish()

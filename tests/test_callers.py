@@ -82,6 +82,45 @@ def test_checkpoint_loader_roundtrip(tmp_path):
             assert torch.equal(getattr(a, name)[i], getattr(b, name)[i]), (name, i)
 
 
+def test_message_converters():
+    """OpenCompass hands the wrappers PromptLists ({"role": HUMAN | BOT | SYSTEM, "prompt": text}); the expected
+    outputs below are what dllm.py:461-501 produces for these inputs (worked out by hand from its rules: role map,
+    empty prompts dropped, consecutive turns of one role joined with a newline; base models: plain concatenation)."""
+    from llada_amd.callers import chat_messages, flat_prompt
+    assert chat_messages("plain question") == [{"role": "user", "content": "plain question"}]
+    pl = [{"role": "SYSTEM", "prompt": "be brief"}, {"role": "HUMAN", "prompt": "Q1"}, {"role": "HUMAN", "prompt": "Q1b"},
+          {"role": "BOT", "prompt": ""}, {"role": "BOT", "prompt": "A1"}, {"role": "HUMAN", "prompt": "Q2"}]
+    assert chat_messages(pl) == [{"role": "system", "content": "be brief"}, {"role": "user", "content": "Q1\nQ1b"},
+                                 {"role": "assistant", "content": "A1"}, {"role": "user", "content": "Q2"}]
+    assert chat_messages(pl, merge_role=False)[1:3] == [{"role": "user", "content": "Q1"}, {"role": "user", "content": "Q1b"}]
+    assert chat_messages([{"role": "BOT", "prompt": ""}], skip_empty_prompt=False) == [{"role": "assistant", "content": ""}]
+    # already-converted chat messages pass through
+    done = [{"role": "user", "content": "x"}, {"role": "assistant", "content": "y"}]
+    assert chat_messages(done) == done
+    with pytest.raises(KeyError):
+        chat_messages([{"role": "NARRATOR", "prompt": "x"}])          # the reference's role table raises KeyError too
+    with pytest.raises(TypeError):
+        chat_messages([{"role": "HUMAN"}])
+    with pytest.raises(TypeError):
+        chat_messages(["not a dict"])
+    assert flat_prompt("as is") == "as is"
+    assert flat_prompt(pl) == "be briefQ1Q1bA1Q2"
+    with pytest.raises(TypeError):
+        flat_prompt([{"role": "HUMAN"}])
+
+
+def test_wrappers_convert_prompt_lists_before_tokenizing():
+    """The wrappers' prompt assembly on PromptList requests, no model needed (dllm.py:373-374, 509-510, 551-554)."""
+    from llada_amd.callers import LLaDABaseModel, LLaDAModel
+    tok = ToyTokenizer()
+    pl = [{"role": "HUMAN", "prompt": "Q"}, {"role": "BOT", "prompt": "A"}, {"role": "HUMAN", "prompt": "R"}]
+    chat = LLaDAModel(model=object(), tokenizer=tok)
+    assert chat._prompts(["hi", pl]) == ["<user>hi</><assistant>", "<user>Q</><assistant>A</><user>R</><assistant>"]
+    base = LLaDABaseModel(model=object(), tokenizer=tok)
+    assert base._prompts(["hi", pl]) == ["hi", "QAR"]
+    assert base.get_token_len(pl) == 4 and base.get_token_len(pl, add_special_tokens=False) == 3
+
+
 @pytest.fixture(scope="module")
 def small_full_vocab_model():
     from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights
@@ -117,13 +156,17 @@ def test_opencompass_wrappers(lib, small_full_vocab_model):
     kw = dict(model=model, tokenizer=tok, gen_steps=16, gen_length=16, gen_blocksize=8, batch_size_=3,
               diff_confidence_eos_eot_inf=True, diff_logits_eos_inf=True)
     inputs = ["short", "a much longer question than the first", "xy"]
-    chat_inputs = inputs[:2] + [[{"role": "user", "content": "x"}, {"role": "assistant", "content": "y"}]]
+    # OpenCompass PromptLists (dllm.py:461-501) next to plain strings and ready chat messages
+    prompt_list = [{"role": "HUMAN", "prompt": "x"}, {"role": "BOT", "prompt": "y"}, {"role": "HUMAN", "prompt": "z"}]
+    chat_inputs = inputs[:1] + [prompt_list] + [[{"role": "user", "content": "x"}, {"role": "assistant", "content": "y"},
+                                                 {"role": "user", "content": "z"}]]
     chat_out = LLaDAModel(**kw).generate(chat_inputs, max_out_len=16)
     assert len(chat_out) == 3 and all(isinstance(r, str) for r in chat_out)
     base = LLaDABaseModel(stop_words=["q", "zz"], **kw)
-    with pytest.raises(TypeError):
-        base.generate(chat_inputs, max_out_len=16)
+    as_lists = base.generate([[{"role": "HUMAN", "prompt": "sho"}, {"role": "HUMAN", "prompt": "rt"}], inputs[1],
+                              [{"role": "HUMAN", "prompt": "xy"}]], max_out_len=16)
     out = base.generate(inputs, max_out_len=16)
+    assert as_lists == out                                                      # "sho" + "rt" is the prompt "short"
     assert len(out) == 3 and all("q" not in r for r in out)
     # same tokens as generate() on the left-padded batch without an attention mask (dllm.py:516-530)
     tok.padding_side = "left"

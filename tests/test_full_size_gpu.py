@@ -46,6 +46,54 @@ def test_generate_single_sequence_invariants(model8b):
     assert torch.equal(out, again)
 
 
+def test_generate_reference_cpu_configuration_shape(model8b):
+    """The configuration the reference's CPU path is quoted on, on the HIP path: batch 1, P = 128, gen_length 64,
+    steps 64, block_length 32, temperature 0, low_confidence (generate.py:74-134).  Every one of the 64 steps
+    reveals exactly one token inside its block (two blocks of 32), a revealed token never changes, two runs are
+    bit-identical, and on two steps (the first of each block) the oracle's epilogue on the HIP forward's own
+    full-vocabulary logits of the step's input gives the same candidates, confidences and transferred token."""
+    from llada_amd import generate
+    B, P, G, bl = 1, 128, 64, 32
+    L = P + G
+    prompt = prompts(B, P, seed=64)
+    trace = []
+    out = generate(model8b, prompt, steps=G, gen_length=G, block_length=bl, temperature=0., remasking="low_confidence",
+                   step_callback=lambda b, s, x, x0, c: trace.append((b, s, x.cpu().numpy().copy(), x0.cpu().numpy().copy(),
+                                                                      c.cpu().numpy().copy())))
+    assert [(t[0], t[1]) for t in trace] == [(n // bl, n % bl) for n in range(G)]
+    start = np.concatenate([prompt[0].numpy(), np.full(G, MASK_ID)])[None, :]
+    prev = start
+    for n, (block, _, x_after, _, _) in enumerate(trace):
+        changed = np.flatnonzero(x_after[0] != prev[0])
+        assert len(changed) == 1, (n, changed)                                       # get_num_transfer_tokens: 32 / 32 = 1
+        assert prev[0, changed[0]] == MASK_ID and x_after[0, changed[0]] != MASK_ID
+        assert P + block * bl <= changed[0] < P + (block + 1) * bl                   # :125 confines it to the block
+        assert (x_after[0, P + (block + 1) * bl:] == MASK_ID).all()
+        prev = x_after
+    o = out.cpu().numpy()
+    assert np.array_equal(o, prev) and np.array_equal(o[0, :P], prompt[0].numpy()) and not (o == MASK_ID).any()
+    again = generate(model8b, prompt, steps=G, gen_length=G, block_length=bl, temperature=0., remasking="low_confidence")
+    assert torch.equal(out, again)
+    for n in (0, bl):                                                                # first step of each block
+        x_in = start if n == 0 else trace[n - 1][2]
+        block = n // bl
+        # logits of the block's positions (every other position's are discarded by generate.py:125-128), asked
+        # for the way generate() asks, so the GEMM plan and hence every rounding is the step's own
+        rows = torch.arange(P + block * bl, P + (block + 1) * bl, dtype=torch.int32).cuda().contiguous()
+        lg = model8b.forward_rows(torch.from_numpy(x_in).cuda(), None, rows).float().cpu().numpy()
+        full = np.zeros((1, L, lg.shape[-1]), dtype=np.float32)
+        full[0, P + block * bl:P + (block + 1) * bl] = lg
+        ox0, oconf = osamp.confidence_step(x_in, full, MASK_ID, P + (block + 1) * bl, "low_confidence")
+        _, _, x_after, x0, conf = trace[n]
+        live = ~np.isneginf(oconf)
+        assert live.sum() == bl and np.array_equal(live, ~np.isneginf(conf))
+        assert np.array_equal(x0[live], ox0[live])
+        assert ((ulp_distance(conf[live], oconf[live]) <= 1) | (np.abs(conf[live] - oconf[live]) <= 2e-2)).all()
+        x_next = x_in.copy()
+        osamp.topk_transfer(x_next, x0, conf, np.ones(1, dtype=np.int64))            # :130-134 on the step's own scores
+        assert np.array_equal(x_next, x_after)
+
+
 def test_generate_batched_padded_schedule(model8b):
     """8 rows (one left-padded with an attention mask), 4 tokens per step: every row reveals exactly
     get_num_transfer_tokens' count per step; sampled runs (temperature, library noise) are

@@ -88,3 +88,32 @@ def test_select_from_cached_scores_manual_tokens_and_rewind(built):
     assert st.rewind(17) is None
     st.step(2)
     assert (st.x == MASK_ID).sum() == G - 3
+
+
+def test_rewind_restores_the_random_stream_and_forced_ids_are_checked(built):
+    """Sampled runs (temperature 0.7, library Philox noise keyed by the forward counter): stepping on after a
+    rewind repeats the original continuation exactly; a forced token outside the vocabulary raises like a prompt
+    id would; ``max_history`` bounds the kept states."""
+    from llada_amd.stepper import GenerationStepper
+    _, _, model = built
+    g = np.random.Generator(np.random.PCG64(8))
+    P, G, bl = 7, 16, 8
+    prompt = torch.from_numpy(g.integers(0, MASK_ID, size=(2, P), dtype=np.int64))
+    st = GenerationStepper(model, prompt, gen_length=G, block_length=bl, temperature=0.7, mask_id=MASK_ID, seed=13)
+    states = [st.x.clone()]
+    for _ in range(6):
+        states.append(st.step(2).clone())
+    assert st.step_index == 6
+    st.rewind(2)
+    assert st.step_index == 2 and torch.equal(st.x, states[2]) and sorted(st.history) == [0, 1, 2]
+    for n in range(3, 7):
+        assert torch.equal(st.step(2), states[n]), n              # same noise as the first time round
+    with pytest.raises(IndexError):
+        st.select(0, manual_selections={(0, P): model.cfg.vocab_size})
+    with pytest.raises(IndexError):
+        st.step(1, manual_selections={(5, P): 3})                 # row outside the batch
+    capped = GenerationStepper(model, prompt, gen_length=G, block_length=bl, mask_id=MASK_ID, max_history=2)
+    for _ in range(5):
+        capped.step(1)
+    assert sorted(capped.history) == [0, 4, 5]
+    assert capped.rewind(2) is None and capped.rewind(4) is not None and capped.step_index == 4
