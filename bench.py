@@ -135,14 +135,27 @@ class _TimedWindowDone(Exception):
     pass
 
 
+def window_start(W_, K_, steps_per_block, steps_total):
+    """First timed step: W_ untimed steps, plus as many more as it takes for the K_ timed steps to contain a block
+    boundary (the per-block work -- schedule kernel, one flag read, buffer set-up -- then falls inside the window, as
+    it does in a whole call), when the call is long enough for that."""
+    if steps_per_block >= steps_total or (W_ // steps_per_block) != ((W_ + K_ - 1) // steps_per_block):
+        return W_
+    start = (W_ // steps_per_block + 1) * steps_per_block - K_ // 2
+    return start if start >= W_ and start + K_ <= steps_total else W_
+
+
 def timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all, on_start=None, row_offset=0, attention_mask=None,
-                **sampler):
-    """Runs generate() (steps == gen_length) and times steps W_ .. W_+K_ of it between two
-    barrier + synchronize pairs; returns seconds for the K_ steps.  ``sampler``: temperature, cfg_scale,
-    remasking, seed of the call (default: temperature 0, no guidance, low_confidence)."""
+                span_block=False, **sampler):
+    """Runs generate() (steps == gen_length) and times K_ consecutive steps of it, after at least W_ untimed ones,
+    between two barrier + synchronize pairs; returns seconds for the K_ steps.  ``span_block``: place the window
+    over a block boundary (window_start).  ``sampler``: temperature, cfg_scale, remasking, seed of the call
+    (default: temperature 0, no guidance, low_confidence)."""
     kw = dict(temperature=0., cfg_scale=0., remasking="low_confidence")
     kw.update(sampler)
     state = {"n": 0, "t0": None, "t1": None}
+    if span_block:
+        W_ = window_start(W_, K_, bl, G)
 
     def begin():
         sync_all()
@@ -360,6 +373,8 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers makes the result INVALID")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency leg")
+    ap.add_argument("--no-whole-call", action="store_true",
+                    help="skip the whole-call cross-check of `value` (one full generate() of the headline configuration)")
     ap.add_argument("--workload", choices=["generate", "likelihood"], default="generate",
                     help="likelihood: get_log_likelihood(mc_num=128, batch_size=32), prompt 256 + answer 128 tokens, the MC rows of "
                          "every iteration split over the ranks and the loss sums all-reduced (strong scaling; a step = one call)")
@@ -438,7 +453,18 @@ def main():
 
     elapsed = timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all,
                           on_start=lambda: lib.llada_gemm_profile_begin(_lib.EPI_SWIGLU, K_ * cfg.n_layers, B * L),
-                          row_offset=row_lo)
+                          row_offset=row_lo, span_block=True)
+    # cross-check of the extrapolation value = rows * G / (steps_total * t_step): one WHOLE generate() call of the
+    # headline configuration, wall clock between barrier + synchronize pairs (every block boundary, allocation
+    # and host read of the call included)
+    whole_call_s = None
+    if not args.no_whole_call:
+        sync_all()
+        t0 = time.perf_counter()
+        generate(model, prompt, None, steps=steps_total, gen_length=G, block_length=bl, temperature=0., cfg_scale=0.,
+                 remasking="low_confidence", row_offset=row_lo)
+        sync_all()
+        whole_call_s = time.perf_counter() - t0
     tot_ms, n_s = C.c_double(0), C.c_int(0)
     lib.llada_gemm_profile_end(C.byref(tot_ms), C.byref(n_s))
     torch.cuda.synchronize()
@@ -448,6 +474,11 @@ def main():
     elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / K_
     tokens_per_s = total_rows * G / (steps_total * ms_per_step * 1e-3)
+    if whole_call_s is not None:
+        tw = torch.tensor([whole_call_s], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        whole_call_s = float(tw.item())
 
     if rank == 0:
         M = B * L
@@ -472,6 +503,8 @@ def main():
             "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": K_, "warmup": W_,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
+            "timed_window": {"first_step": window_start(W_, K_, bl, G), "steps": K_, "steps_per_block": bl,
+                             "spans_block_boundary": window_start(W_, K_, bl, G) // bl != (window_start(W_, K_, bl, G) + K_ - 1) // bl},
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"LLaDA-8B generate(): {total_rows} prompts dealt over {world} GPU(s) ({B} on rank 0) x P={P}, "
                                     if strong else f"LLaDA-8B generate(): {B} prompts/GPU x P={P}, ")
@@ -488,14 +521,32 @@ def main():
                          "launches_timed": n_s.value, "avg_launch_ms": round(gemm_ms, 4),
                          "flops_per_launch": gemm_flops},
         }
+        if whole_call_s is not None:
+            v_whole = total_rows * G / whole_call_s
+            rec["whole_call_s"] = round(whole_call_s, 4)
+            rec["value_from_whole_call"] = round(v_whole, 3)
+            rec["whole_call_vs_value"] = round(v_whole / tokens_per_s, 4)
+            if abs(v_whole / tokens_per_s - 1.0) > 0.03:
+                sys.exit(f"bench.py: value extrapolated from {K_} timed steps ({tokens_per_s:.2f} tokens/s) and the whole "
+                         f"{steps_total}-step call ({v_whole:.2f} tokens/s) differ by more than 3 %: " + json.dumps(rec))
         rec["measured_ceilings"] = measured_ceilings(torch, device, M, 2 * F, d)
         rec["epilogue_roofline"] = epilogue_roofline(torch, lib, _lib, device, R, V, cfg.mask_token_id)
         if world == 1 and B != 1 and not args.no_latency:
             # the single-sequence configuration (batch 1, same gen_length / steps / block_length):
             # per-step latency of forward + epilogue
-            t1 = timed_steps(generate, model, prompt[:1], G, bl, W_, K_, sync_all)
-            rec["latency_batch1"] = {"ms_per_step": round(1e3 * t1 / K_, 4), "tokens_per_s": round(G / (steps_total * t1 / K_), 2),
-                                     "workload": f"1 prompt x P={P}, gen_length={G}, steps={steps_total}, block_length={bl}"}
+            t1 = timed_steps(generate, model, prompt[:1], G, bl, W_, K_, sync_all, span_block=True)
+            s1 = t1 / K_
+            # one sequence sits on the ridge: report it against both bounds.  Bytes = every weight matrix read once
+            # (the LM head and the last layer's three late projections serve only the block's rows, but their
+            # weights are still read whole); FLOPs = those actually executed.
+            w_bytes = 2.0 * cfg.linear_params()
+            fl1 = 2.0 * L * lin + 2.0 * bl * (d * d + 3 * d * F) + 2.0 * bl * d * V + L * 4.0 * L * d * cfg.n_layers
+            rec["latency_batch1"] = {"ms_per_step": round(1e3 * s1, 4), "tokens_per_s": round(G / (steps_total * s1), 2),
+                                     "workload": f"1 prompt x P={P}, gen_length={G}, steps={steps_total}, block_length={bl}",
+                                     "roofline": {"weights_GBps": round(w_bytes / s1 / 1e9, 1), "frac_hbm": round(w_bytes / s1 / 8e12, 4),
+                                                  "tflops_executed": round(fl1 / 1e12, 3),
+                                                  "frac_mfma": round(fl1 / s1 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                  "weight_bytes_per_step": w_bytes}}
         if world == 1 and not args.no_latency:
             # opt-in approximation outside the reference (cache="dual"): whole generate() calls, wall clock
             def whole_call(p_):
@@ -517,6 +568,22 @@ def main():
             rec["other_configs"] = other_configs(torch, generate, model, cfg, sync_all)
         if world == 1 and not args.no_cpu_baseline:      # the host baseline is reported at N = 1 only
             rec["cpu_baseline"] = cpu_baseline(cfg)
+            # the same configuration on the HIP path (BASELINE configuration 1: batch 1, P = 128, gen_length 64,
+            # steps 64, block_length 32): a whole call, wall clock.  `value` above is another workload (8 rows per
+            # GPU, gen_length 256); this is the like-for-like pair of the host number.
+            p1 = prompt[:1, :128] if P >= 128 else prompt[:1]
+            generate(model, p1, None, steps=64, gen_length=64, block_length=32, temperature=0., remasking="low_confidence")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            generate(model, p1, None, steps=64, gen_length=64, block_length=32, temperature=0., remasking="low_confidence")
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - t0
+            rec["cpu_baseline"]["comparable_to"] = "cpu_baseline.gpu_same_config (NOT `value`, which is 8 rows per GPU at gen_length 256)"
+            rec["cpu_baseline"]["gpu_same_config"] = {"tokens_per_s": round(64 / tg, 2), "ms_per_step": round(1e3 * tg / 64, 3),
+                                                      "seconds_per_call": round(tg, 4),
+                                                      "workload": "batch 1, P=128, gen_length=64, steps=64, block_length=32, T=0, "
+                                                                  "low_confidence: one whole generate() call on the HIP path"}
+            rec["cpu_baseline"]["speedup_same_config"] = round((64 / tg) / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

@@ -62,8 +62,10 @@ def generate_data_parallel(generate_fn, model, prompt, attention_mask=None, *arg
 def combine_loss_sums(loss_sums, batch_size, world_size=1, process_group=None):
     """get_log_likelihood.py:73-77 across ranks: ``loss_sums`` [n_iter] float64 holds this rank's
     sum of CE/p_mask per iteration; one all-reduce(sum), then loss = sum / batch_size per
-    iteration and the result is minus their mean.  The only host synchronisation of the call."""
-    if world_size > 1:
+    iteration and the result is minus their mean.  The only host synchronisation of the call.
+    The all-reduce also runs for a one-rank group when a ``process_group`` is named (a no-op numerically; it keeps
+    the single-rank call on the same code path as the sharded one)."""
+    if world_size > 1 or process_group is not None:
         if loss_sums.is_cuda and dist.get_backend(process_group) == "gloo":
             loss_sums = loss_sums.cpu()        # a CPU-only process group (rehearsals): reduce on the host
         dist.all_reduce(loss_sums, op=dist.ReduceOp.SUM, group=process_group)

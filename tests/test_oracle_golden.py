@@ -176,3 +176,46 @@ def test_likelihood(case):
     assert abs(val - ref) <= 1e-3 * abs(ref), (val, ref)
     # bf16-rounded per-token CE makes the two agree far more tightly than the contract asks
     assert abs(val - ref) <= 2e-5 * abs(ref), (val, ref)
+
+
+def _f32lse_cases():
+    return load("sampler_f32lse.npz")[1]
+
+
+@pytest.mark.parametrize("case", _f32lse_cases(), ids=lambda c: c["name"])
+def test_entropy_rules_float32_softmax_runs(case):
+    """The entropy rules against reference runs whose F.softmax / F.log_softmax computed in float32 and rounded
+    once to bf16 (what torch's GPU kernels do for a bf16 tensor; tools/make_golden.py::Float32Softmax): the oracle's
+    DEFAULT branch (torch_cpu=False, the form the HIP kernel implements) reproduces every step's scores to one
+    bf16 ulp, the reference's transfers are a valid top-k of them, and the committed tokens are its candidates.
+    (Entropies below 2^-16 are compared absolutely, to 2^-22: when one token holds all the mass its term is
+    log(1 + eps) with eps near float32's resolution at 1, so the last bits depend on the order in which the row's
+    float32 sum was taken -- a 2-ulp difference of a 8.5e-6 entropy is the one such value in these runs.)"""
+    z, _ = load("sampler_f32lse.npz")
+    n = case["name"]
+    xs = z[f"{n}/x_steps"].astype(np.int64)
+    ks = z[f"{n}/k"]
+    conf_ref = case_confidence(z, n)
+    B, L = xs.shape[1], xs.shape[2]
+    P, bl = case["P"], case["bl"]
+    steps_per_block = case["steps"] // (case["G"] // bl)
+    draws = Draws(case["seed"] + 5000)
+    worst = 0
+    for t in range(xs.shape[0] - 1):
+        nb = t // steps_per_block
+        logits = _step_logits(case, t, B, L)
+        u = draws.rand_like(logits.shape) if case["T"] != 0 else None
+        x0, conf = osamp.confidence_step(xs[t], logits, MASK_ID, P + (nb + 1) * bl, case["remasking"], case["T"], u,
+                                         None, case["eos_inf"], case["conf_inf"])
+        cr = conf_ref[t]
+        assert np.array_equal(np.isneginf(conf), np.isneginf(cr)) and np.array_equal(np.isnan(conf), np.isnan(cr))
+        fin = np.isfinite(cr)
+        tiny = fin & (np.abs(cr) < 2.0 ** -16)
+        assert np.abs(conf[tiny] - cr[tiny]).max(initial=0) <= 2.0 ** -22
+        fin &= ~tiny
+        worst = max(worst, int(ulp_distance(conf[fin], cr[fin]).max(initial=0)))
+        changed = xs[t + 1] != xs[t]
+        for j in range(B):
+            assert osamp.is_valid_topk(cr[j], changed[j], ks[t, j])
+        assert np.array_equal(xs[t + 1][changed], x0[changed])
+    assert worst <= 1, worst

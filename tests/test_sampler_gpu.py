@@ -161,6 +161,48 @@ def test_remask_step_teacher_forced(lib, case, sampler_z):
             assert np.array_equal(changed, ref_changed)         # identical to the reference's transfer set
 
 
+def _f32lse_cases():
+    return load("sampler_f32lse.npz")[1]
+
+
+@pytest.mark.parametrize("case", _f32lse_cases(), ids=lambda c: c["name"])
+def test_entropy_rules_against_float32_softmax_reference_runs(lib, case):
+    """The two entropy rules pinned to the reference: runs of generate.py whose F.softmax / F.log_softmax computed in
+    float32 and rounded once to bf16 (torch's GPU arithmetic for a bf16 tensor; tests/golden/sampler_f32lse.npz,
+    tools/make_golden.py::Float32Softmax).  Every step: the kernel's scores equal the recorded ones to one bf16 ulp
+    (entropies below 2^-16 absolutely, to 2^-22: log(1 + eps) of a float32 sum), candidates are the oracle's, and the
+    top-k transfer on the kernel's own scores is a valid reference transfer set wherever the boundary has no tie."""
+    z, _ = load("sampler_f32lse.npz")
+    n = case["name"]
+    xs = z[f"{n}/x_steps"].astype(np.int64)
+    ks = z[f"{n}/k"]
+    conf_ref = case_confidence(z, n)
+    B, L = xs.shape[1], xs.shape[2]
+    P, bl, V = case["P"], case["bl"], case["V"]
+    spb = case["steps"] // (case["G"] // bl)
+    draws = Draws(case["seed"] + 5000)
+    for t in range(xs.shape[0] - 1):
+        be = P + (t // spb + 1) * bl
+        Be = 2 * B if case["cfg"] > 0 else B
+        lg = fake_model_logits(case["seed"], t, (Be, L, V))
+        u = draws.rand_like((B, L, V)) if case["T"] != 0 else None
+        x0, conf = remask(lib, lg[:B].reshape(B * L, V), lg[B:].reshape(B * L, V) if case["cfg"] > 0 else None, case["cfg"],
+                          xs[t], be, case["remasking"], 0, case["T"], None if u is None else u.reshape(B * L, V))
+        cr = conf_ref[t].astype(np.float32)
+        assert np.array_equal(np.isneginf(conf), np.isneginf(cr)) and np.array_equal(np.isnan(conf), np.isnan(cr))
+        fin = np.isfinite(cr)
+        tiny = fin & (np.abs(cr) < 2.0 ** -16)
+        assert np.abs(conf[tiny] - cr[tiny]).max(initial=0.0) <= 2.0 ** -22
+        assert ulp_distance(conf[fin & ~tiny], cr[fin & ~tiny]).max(initial=0) <= 1
+        changed = xs[t + 1] != xs[t]
+        assert np.array_equal(x0[changed], xs[t + 1][changed])                   # the committed tokens are its candidates
+        if all(_no_boundary_tie(cr[j], ks[t, j]) and _no_boundary_tie(conf[j], ks[t, j]) for j in range(B)) \
+                and ulp_distance(conf[fin], cr[fin]).max(initial=0) == 0:
+            want = xs[t].copy()
+            osamp.topk_transfer(want, x0, conf, ks[t])
+            assert np.array_equal(want, xs[t + 1])
+
+
 def _no_boundary_tie(row, k):
     k = int(k)
     if np.isnan(row).any():
@@ -354,7 +396,7 @@ def test_generate_matches_reference_runs(lib, sampler_z):
         conf = case_confidence(z, n)
         ks = z[f"{n}/k"]
         if case["remasking"] in ("low_entropy", "high_entropy"):
-            continue      # golden entropy confidences carry torch's CPU-only rounding (see oracle.sampler)
+            continue      # these runs went through torch's CPU-only bf16 log-sum-exp; see the float32-softmax runs below
         if not all(_no_boundary_tie(conf[t, j], ks[t, j]) for t in range(conf.shape[0]) for j in range(conf.shape[1])):
             continue
         total += 1
@@ -371,6 +413,31 @@ def test_generate_matches_reference_runs(lib, sampler_z):
         exact += np.array_equal(out.cpu().numpy(), z[f"{n}/final"])
     assert total >= 30
     assert exact >= total - 2, (exact, total)    # a 1-ulp confidence difference may flip a near tie
+
+
+def test_generate_matches_float32_softmax_entropy_runs(lib):
+    """llada_amd.generate() end to end with the entropy rules against the reference runs whose softmax pair computed
+    in float32 (sampler_f32lse.npz): the final sequences are the reference's wherever no step had a tie at its top-k
+    boundary (a 1-ulp score difference may still flip a near tie: a handful of runs are allowed to differ)."""
+    from llada_amd import generate
+    z, meta = load("sampler_f32lse.npz")
+    exact = total = 0
+    for case in meta:
+        n = case["name"]
+        conf = case_confidence(z, n)
+        ks = z[f"{n}/k"]
+        if not all(_no_boundary_tie(conf[t, j], ks[t, j]) for t in range(conf.shape[0]) for j in range(conf.shape[1])):
+            continue
+        total += 1
+        model = TorchFakeModel(case["seed"], case["V"])
+        draws = Draws(case["seed"] + 5000)
+        am = torch.from_numpy(z[f"{n}/attention_mask"]) if f"{n}/attention_mask" in z.files else None
+        out = generate(model, torch.from_numpy(z[f"{n}/prompt"]), am, steps=case["steps"], gen_length=case["G"],
+                       block_length=case["bl"], temperature=case["T"], cfg_scale=case["cfg"], remasking=case["remasking"],
+                       mask_id=MASK_ID, noise_fn=lambda s: torch.from_numpy(draws.rand_like(s)))
+        exact += np.array_equal(out.cpu().numpy(), z[f"{n}/final"])
+    assert total >= 20, total
+    assert exact >= total - 2, (exact, total)
 
 
 def test_generate_errors(lib):
