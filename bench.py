@@ -271,6 +271,20 @@ def other_configs(torch, generate, model, cfg, sync_all):
     sync_all()
     out["likelihood_mc128_bs32"] = {"ms_per_call": round(1e3 * (time.perf_counter() - t0), 2), "log_likelihood": round(val, 4),
                                     "workload": "get_log_likelihood(): prompt 256 + answer 128 tokens, mc_num=128, batch_size=32, one GPU"}
+    # one rank's share of the same call split over 8 GPUs (4 of the 32 rows of each of the 4 iterations), run alone on
+    # this GPU: one fused forward of 16 rows against one forward of 4 rows per iteration
+    share = {}
+    for tag, fuse in (("fused_forward", True), ("forward_per_iteration", False)):
+        kw = dict(mc_num=128, batch_size=32, seed=7, rank=3, world_size=8, return_loss_sums=True, fuse_iterations=fuse)
+        sums = get_log_likelihood(model, p_ids, a_ids, **kw)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sums = get_log_likelihood(model, p_ids, a_ids, **kw)
+        sync_all()
+        share[tag] = {"ms_per_call": round(1e3 * (time.perf_counter() - t0) / 3, 2), "loss_sums": [round(float(v), 3) for v in sums.cpu()]}
+    share["workload"] = "rank 3 of 8 of the call above (4 rows x 4 iterations x 384 tokens), alone on one GPU"
+    out["likelihood_mc128_bs32_one_rank_of_8"] = share
     return out
 
 

@@ -17,6 +17,9 @@ from .model import LLaDAModel, check_token_ids
 from .parallel import combine_loss_sums, shard_bounds
 
 
+FUSED_FORWARD_MAX_ROWS = 64     # sequences per fused forward (get_log_likelihood(fuse_iterations=True))
+
+
 def stratified_counts(k, b, target_len):
     """get_log_likelihood.py:13-14: round(linspace(k, k+(b-1)*(T/b), b)) in float32 (torch.linspace
     evaluates start + i*step in the first half and end - (b-1-i)*step in the second),
@@ -59,7 +62,7 @@ def forward_process(batch, prompt_index, mask_id, *, k=None, perms=None, seed=0,
 @torch.no_grad()
 def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_scale=0., mask_id=126336, *,
                        seed=0, k_fn=None, perm_fn=None, round_ce_bf16=True, rank=0, world_size=1,
-                       process_group=None, return_loss_sums=False):
+                       process_group=None, return_loss_sums=False, fuse_iterations=True):
     '''
     Args (get_log_likelihood.py:48-59):
         model: Mask predictor.  prompt: tensor (l1).  answer: tensor (l2).
@@ -74,6 +77,10 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
             rows over ranks; the per-iteration loss sums are all-reduced once at the end.
         return_loss_sums: return this rank's per-iteration sums of CE / p_mask (float64 device tensor
             [mc_num // batch_size]) instead of reducing them: the rank's contribution before the all-reduce.
+        fuse_iterations: when this rank's rows of ALL iterations together are at most FUSED_FORWARD_MAX_ROWS
+            sequences (the batch split over many GPUs: 4 iterations x 4 rows at mc_num 128, batch_size 32 on 8
+            GPUs), run them through one forward instead of one per iteration (:66-70 loop; the rows are
+            independent).  Same masks and sums; False keeps one forward per iteration.
     '''
     lib = _lib.load()
     device = torch.device(model.device)
@@ -125,7 +132,47 @@ def get_log_likelihood(model, prompt, answer, mc_num=128, batch_size=16, cfg_sca
         row_loss = torch.empty(n_ans if fast else b_loc * l, dtype=torch.float32, device=device)
         ws = torch.empty(lib.llada_rows_workspace_bytes(row_loss.numel()), dtype=torch.uint8, device=device)
         stream = _lib.stream_ptr()
-        for it in range(n_iter):
+        # Few rows per rank (the batch split over many GPUs): all iterations of this rank share ONE forward.  Every
+        # iteration's masks, masked positions, p_mask and loss sum are exactly those of the loop below; only the
+        # number of rows per forward differs (other GEMM tilings, i.e. the last bits of the bf16 roundings).
+        n_seq_all = n_iter * b_loc * (2 if cfg_scale > 0. else 1)
+        if fast and fuse_iterations and n_iter > 1 and n_seq_all <= FUSED_FORWARD_MAX_ROWS:
+            noisy_all = torch.empty((n_iter * b_loc, l), dtype=torch.long, device=device)
+            rows_all = torch.empty(int(masked_per_iter.sum()), dtype=torch.int32, device=device)
+            offs = np.concatenate([[0], np.cumsum(masked_per_iter)]).astype(np.int64)
+            for it in range(n_iter):
+                noisy_it = noisy_all[it * b_loc:(it + 1) * b_loc]
+                _lib.check(lib.llada_ll_mask(seq_loc.data_ptr(), noisy_it.data_ptr(), b_loc, l, l1, mask_id,
+                                             counts_t[it].data_ptr(), None if perms_t is None else perms_t[it].data_ptr(),
+                                             seed, it, r0, stream))                             # :67
+                _lib.check(lib.llada_ll_masked_rows(noisy_it.data_ptr(), b_loc, l, l1, mask_id, counts_t[it].data_ptr(),
+                                                    rows_all[int(offs[it]):].data_ptr(), stream))
+            # token indices inside the iteration's own rows (the cross-entropy kernel's view) and inside the fused batch
+            rows_fwd = rows_all + torch.repeat_interleave(
+                torch.arange(n_iter, device=device, dtype=torch.int32) * (b_loc * l),
+                torch.from_numpy(masked_per_iter).to(device))
+            n_all = rows_all.numel()
+            if cfg_scale > 0.:                                                                  # :30-35
+                un_all = noisy_all.clone()
+                un_all[:, :l1] = mask_id
+                batch = torch.cat([noisy_all, un_all])
+                rows_fwd = torch.cat([rows_fwd, rows_fwd + n_iter * b_loc * l])
+            else:
+                batch = noisy_all
+            lg = model.forward_rows(batch, None, rows_fwd.contiguous())                         # :38, once
+            for it in range(n_iter):
+                o0, n_rows = int(offs[it]), int(masked_per_iter[it])
+                cond = lg[o0:o0 + n_rows]
+                un_ptr = lg[n_all + o0:n_all + o0 + n_rows].data_ptr() if cfg_scale > 0. else None
+                _lib.check(lib.llada_masked_ce(cond.data_ptr(), un_ptr, float(cfg_scale), rows_all[o0:].data_ptr(), n_rows,
+                                               cond.shape[-1], noisy_all[it * b_loc:].data_ptr(), seq_loc.data_ptr(), b_loc, l,
+                                               mask_id, pmask_t[it].data_ptr(), 1 if round_ce_bf16 else 0,
+                                               row_loss.data_ptr(), loss_sums[it:].data_ptr(), ws.data_ptr(), ws.numel(),
+                                               stream))                                         # :72
+            n_iter_loop = 0
+        else:
+            n_iter_loop = n_iter
+        for it in range(n_iter_loop):
             _lib.check(lib.llada_ll_mask(seq_loc.data_ptr(), noisy.data_ptr(), b_loc, l, l1, mask_id,
                                          counts_t[it].data_ptr(), None if perms_t is None else perms_t[it].data_ptr(),
                                          seed, it, r0, stream))                                 # :67

@@ -173,6 +173,24 @@ def test_likelihood_mc128_batch32(model8b):
     assert abs(-(whole / 32).mean() - a) <= 1e-12 * abs(a)
 
 
+def test_likelihood_mc128_batch32_eight_rank_shares(model8b):
+    """The same call split over 8 ranks, run rank by rank on this GPU: every rank holds 4 of the 32 rows of each of
+    the 4 iterations and runs its 16 rows through ONE forward (fuse_iterations).  The eight ranks' per-iteration sums
+    add up to the single-rank sums within 1e-4 (GEMM tilings of 16 x 384 instead of 32 x 384 rows), and one rank's
+    fused sums agree with its own per-iteration loop to the same bound."""
+    from llada_amd import get_log_likelihood
+    g = np.random.Generator(np.random.PCG64(4321))
+    prompt = torch.from_numpy(g.integers(0, 126000, size=256, dtype=np.int64))
+    answer = torch.from_numpy(g.integers(0, 126000, size=128, dtype=np.int64))
+    kw = dict(mc_num=128, batch_size=32, seed=7, return_loss_sums=True)
+    whole = get_log_likelihood(model8b, prompt, answer, **kw).cpu().numpy()
+    parts = [get_log_likelihood(model8b, prompt, answer, rank=r, world_size=8, **kw).cpu().numpy() for r in range(8)]
+    rel = np.abs(sum(parts) - whole) / np.abs(whole)
+    assert rel.max() <= 1e-4, rel
+    loop3 = get_log_likelihood(model8b, prompt, answer, rank=3, world_size=8, fuse_iterations=False, **kw).cpu().numpy()
+    assert (np.abs(parts[3] - loop3) / np.abs(loop3)).max() <= 1e-4
+
+
 class TableModel:
     """Protocol-only model (generate.py:60,88,92) whose logits depend on nothing but the token and its position, so
     a row's logits are the same whatever batch it sits in: what is left to differ between rank counts is the

@@ -161,3 +161,34 @@ def test_ll_masked_rows(lib):
     got = out.cpu().numpy()
     assert np.array_equal(got[: want.size], want)
     assert (got[want.size:] == -1).all()
+
+
+def test_fused_iterations_give_the_per_iteration_sums(lib):
+    """A rank that holds few rows runs all its Monte-Carlo iterations through one forward
+    (get_log_likelihood(fuse_iterations=True), the default): masks, masked positions and p_mask are those of the
+    per-iteration loop (get_log_likelihood.py:66-75), so each iteration's loss sum agrees with the loop's up to the
+    bf16 rounding noise of another GEMM tiling -- with and without guidance, and as one rank of a split batch."""
+    import torch
+    from llada_amd import get_log_likelihood
+    from tests import fuzz_util
+    _, _, model = fuzz_util.build_model()
+    g = np.random.Generator(np.random.PCG64(31))
+    prompt = torch.from_numpy(g.integers(0, fuzz_util.MASK_ID, size=21, dtype=np.int64))
+    answer = torch.from_numpy(g.integers(0, fuzz_util.MASK_ID, size=13, dtype=np.int64))
+    for cfg, extra in ((0.0, {}), (1.5, {}), (0.0, dict(rank=1, world_size=3))):
+        kw = dict(mc_num=24, batch_size=6, cfg_scale=cfg, mask_id=fuzz_util.MASK_ID, seed=5, return_loss_sums=True, **extra)
+        loop = get_log_likelihood(model, prompt, answer, fuse_iterations=False, **kw).cpu().numpy()
+        fused = get_log_likelihood(model, prompt, answer, fuse_iterations=True, **kw).cpu().numpy()
+        assert loop.shape == fused.shape == (4,) and (loop > 0).all()
+        assert np.abs(fused - loop).max() <= 2e-3 * np.abs(loop).max(), (cfg, extra, fused, loop)
+    a = get_log_likelihood(model, prompt, answer, mc_num=24, batch_size=6, mask_id=fuzz_util.MASK_ID, seed=5)
+    b = get_log_likelihood(model, prompt, answer, mc_num=24, batch_size=6, mask_id=fuzz_util.MASK_ID, seed=5, fuse_iterations=False)
+    assert abs(a - b) <= 1e-3 * abs(b)
+    # injected masks (k_fn / perm_fn) take the same route
+    ks, perms = [3, 9, 1, 13], [g.permutation(13) for _ in range(24)]
+    outs = []
+    for fuse in (True, False):
+        k1, p1 = list(ks), iter(perms)
+        outs.append(get_log_likelihood(model, prompt, answer, mc_num=24, batch_size=6, mask_id=fuzz_util.MASK_ID,
+                                       k_fn=lambda T: k1.pop(0), perm_fn=lambda T: next(p1), fuse_iterations=fuse))
+    assert abs(outs[0] - outs[1]) <= 1e-3 * abs(outs[1])
