@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LLADA_ABI_VERSION 3
+#define LLADA_ABI_VERSION 4
 
 #define LLADA_OK 0
 #define LLADA_ERR_INVALID (-1)      /* bad argument (the Python host raises AssertionError/ValueError) */
@@ -121,6 +121,19 @@ int llada_forward(const llada_config* cfg, const llada_weights* w, const int64_t
                   const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
                   const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* llada_forward with the rotary position of every token given by the caller: positions [n_seq * seq_len] int32,
+ * the row of rope_cos / rope_sin each token is rotated with (values outside [0, seq_len) are clamped), or NULL for
+ * the token's index inside its sequence.  The reference model always rotates by the column index (`arange(L)`
+ * whatever the padding), and rotary attention depends on position differences only, so a left-padded row gives the
+ * same logits up to rounding with either numbering; numbering every row from its first real token (together with a
+ * key_mask over the padding) makes the rotated queries and keys of a row in a left-padded batch the very values the
+ * row has when it is run alone -- what a caller needs to batch requests that /root/reference/eval_llada.py:260-265
+ * runs one at a time and still reproduce their results. */
+int llada_forward_positions(const llada_config* cfg, const llada_weights* w, const int64_t* ids, const uint8_t* key_mask,
+                            const int32_t* positions, const float* rope_cos, const float* rope_sin, int32_t n_seq,
+                            int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ----- the forward's building blocks, exported for per-kernel parity tests and benches ----- */
 

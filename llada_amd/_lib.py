@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLADA_HIP_LIB") or os.path.join(_HERE, "libllada_hip.so")   # override: A/B timing of two builds
 
-ABI_VERSION = 3     # LLADA_ABI_VERSION of include/llada_hip.h this binding was written for
+ABI_VERSION = 4     # LLADA_ABI_VERSION of include/llada_hip.h this binding was written for
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
 
@@ -51,6 +51,8 @@ SIGNATURES = {
     "llada_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32]),
     "llada_forward": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32, vp,
                                 C.c_int32, vp, vp, C.c_size_t, vp]),
+    "llada_forward_positions": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp,
+                                          C.c_int32, vp, vp, C.c_size_t, vp]),
     "llada_embed_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_gather_rows_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_int64, vp]),
     "llada_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp, vp]),

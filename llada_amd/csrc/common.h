@@ -89,3 +89,15 @@ void llada_set_error(const char* fmt, ...);
             return LLADA_ERR_HIP;                                                   \
         }                                                                           \
     } while (0)
+
+// ---- internal entry points (C++ linkage, not exported) --------------------------------------------
+// llada_gemm_bf16 with the rotary table row of every output row given explicitly (positions [M] int32, or
+// nullptr for token index % seq_len; values are clamped into [0, seq_len)): the ROPE_QKV epilogue of a
+// left-padded batch whose rows count positions from their first real token.
+int llada_gemm_bf16_positions(const void* A, const void* W, void* C, int64_t M, int32_t N, int32_t K, int32_t lda,
+                              int32_t ldc, int32_t epilogue, const void* aux, int32_t ldr, const float* rope_cos,
+                              const float* rope_sin, int32_t seq_len, const int32_t* positions, void* workspace,
+                              size_t workspace_bytes, void* stream);
+// llada_rope_bf16 with explicit positions (the unfused weight layout).
+int llada_rope_bf16_positions(void* qkv, const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
+                              int32_t n_heads, const int32_t* positions, void* stream);

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const bf16_t* __restrict__
 
 // ---- rotary embedding, natural head layout (pairs j, j+64), in place on Q and K -----------------
 __global__ void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cs, const float* __restrict__ sn,
-                            int64_t n_tokens, int L, int H) {
+                            int64_t n_tokens, int L, int H, const int* __restrict__ positions) {
     // one thread per (token, q/k, head, 8 frequencies)
     const int64_t total = n_tokens * 2 * H * 8;
     const int d = H * 128;
@@ -94,7 +94,7 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ 
         const int h = (int)((i >> 3) % H);
         const int qk = (int)((i / (8 * (int64_t)H)) & 1);
         const int64_t m = i / (16 * (int64_t)H);
-        const int pos = (int)(m % L);
+        const int pos = positions ? min(max(positions[m], 0), L - 1) : (int)(m % L);
         bf16_t* p = qkv + m * 3 * d + (size_t)qk * d + h * 128 + c * 8;
         const u16x8 a = *(const u16x8*)p;
         const u16x8 b = *(const u16x8*)(p + 64);
@@ -173,12 +173,17 @@ extern "C" int llada_rmsnorm_bf16(const void* x, const void* w, void* out, int64
 
 extern "C" int llada_rope_bf16(void* qkv, const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
                                int32_t n_heads, void* stream) {
+    return llada_rope_bf16_positions(qkv, rope_cos, rope_sin, n_seq, seq_len, n_heads, nullptr, stream);
+}
+
+int llada_rope_bf16_positions(void* qkv, const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
+                              int32_t n_heads, const int32_t* positions, void* stream) {
     LLADA_CHECK_ARG(qkv && rope_cos && rope_sin && n_seq > 0 && seq_len > 0 && n_heads > 0, "rope: bad argument");
     const int64_t n_tokens = (int64_t)n_seq * seq_len;
     const int64_t total = n_tokens * 16 * n_heads;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, rope_cos, rope_sin,
-                       n_tokens, seq_len, n_heads);
+                       n_tokens, seq_len, n_heads, positions);
     LLADA_CHECK_LAUNCH("rope_kernel");
     return LLADA_OK;
 }

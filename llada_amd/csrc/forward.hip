@@ -79,16 +79,25 @@ __global__ void __launch_bounds__(256) scatter_kv_kernel(const bf16_t* __restric
 int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t* ids, const uint8_t* key_mask,
                  const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
                  const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,
-                 size_t workspace_bytes, void* kv_cache, void* stream);
+                 size_t workspace_bytes, void* kv_cache, const int32_t* positions, void* stream);
 
 }  // namespace
+
+extern "C" int llada_forward_positions(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
+                                       const uint8_t* key_mask, const int32_t* positions, const float* rope_cos,
+                                       const float* rope_sin, int32_t n_seq, int32_t seq_len, const int32_t* logit_rows,
+                                       int32_t n_logit_rows, void* logits_out, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    return forward_impl(cfg, w, ids, key_mask, rope_cos, rope_sin, n_seq, seq_len, logit_rows, n_logit_rows, logits_out,
+                        workspace, workspace_bytes, nullptr, positions, stream);
+}
 
 extern "C" int llada_forward(const llada_config* cfg, const llada_weights* w, const int64_t* ids,
                              const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                              int32_t seq_len, const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out,
                              void* workspace, size_t workspace_bytes, void* stream) {
     return forward_impl(cfg, w, ids, key_mask, rope_cos, rope_sin, n_seq, seq_len, logit_rows, n_logit_rows, logits_out,
-                        workspace, workspace_bytes, nullptr, stream);
+                        workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
 extern "C" size_t llada_kv_cache_bytes(const llada_config* cfg, int32_t n_seq, int32_t seq_len) {
@@ -103,7 +112,7 @@ extern "C" int llada_forward_fill_cache(const llada_config* cfg, const llada_wei
                                         void* stream) {
     LLADA_CHECK_ARG(kv_cache != nullptr && ((uintptr_t)kv_cache & 255) == 0, "forward_fill_cache: kv_cache must be 256-byte aligned");
     return forward_impl(cfg, w, ids, key_mask, rope_cos, rope_sin, n_seq, seq_len, logit_rows, n_logit_rows, logits_out,
-                        workspace, workspace_bytes, kv_cache, stream);
+                        workspace, workspace_bytes, kv_cache, nullptr, stream);
 }
 
 namespace {
@@ -111,7 +120,7 @@ namespace {
 int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t* ids, const uint8_t* key_mask,
                  const float* rope_cos, const float* rope_sin, int32_t n_seq, int32_t seq_len,
                  const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,
-                 size_t workspace_bytes, void* kv_cache, void* stream) {
+                 size_t workspace_bytes, void* kv_cache, const int32_t* positions, void* stream) {
     LLADA_CHECK_ARG(cfg && w && ids && rope_cos && rope_sin && logits_out && workspace, "forward: null argument");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && n_logit_rows > 0, "forward: bad shape");
     const llada_config& c = *cfg;
@@ -159,12 +168,12 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
         // with a cache every layer leaves its [Q | K | V] image there instead of in the shared scratch
         if (kv_cache) qkv = (unsigned char*)kv_cache + (size_t)l * M * 3 * d * 2;
         if (w->packed & 1) {
-            TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV | tf, nullptr, 0, rope_cos,
-                                rope_sin, seq_len, sk, skb, stream));
+            TRY(llada_gemm_bf16_positions(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_ROPE_QKV | tf, nullptr, 0,
+                                          rope_cos, rope_sin, seq_len, positions, sk, skb, stream));
         } else {
             TRY(llada_gemm_bf16(h, w->wqkv[l], qkv, M, 3 * d, d, d, 3 * d, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr,
                                 nullptr, 0, sk, skb, stream));
-            TRY(llada_rope_bf16(qkv, rope_cos, rope_sin, n_seq, seq_len, c.n_heads, stream));
+            TRY(llada_rope_bf16_positions(qkv, rope_cos, rope_sin, n_seq, seq_len, c.n_heads, positions, stream));
         }
         TRY(llada_attn_bidir_bf16(qkv, key_mask, att, n_seq, seq_len, c.n_heads, stream));
         int64_t Ml = M;      // rows from here to the end of the layer

@@ -41,6 +41,7 @@ struct GemmParams {
     int lda, ldc, ldr;
     int tiles_m, tiles_n;
     int seq_len;
+    const int* positions;  // [M] rotary table row of every token, or nullptr: row = token index % seq_len
     int rope_cols;  // columns < rope_cols get the rotary embedding (2 * d_model)
     float* slab;    // split-K partial sums [splits][M][N] float32, or nullptr
     int splits;     // K is cut into `splits` equal ranges, one workgroup each per output tile
@@ -66,6 +67,15 @@ struct GemmParams {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Rotary table row of output row m (clamped into the matrix): the token's index inside its sequence, or the
+// caller's own position (left-padded batches: the first real token of every row is position 0), clamped into
+// the table.
+__device__ __forceinline__ int rope_row(const GemmParams& p, int m) {
+    const int mm = min(m, (int)p.M - 1);
+    if (p.positions) return min(max(p.positions[mm], 0), p.seq_len - 1);
+    return mm % p.seq_len;
+}
 
 __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_uniform) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_uniform, 16, 0, 0);
@@ -176,7 +186,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[MFR
 #pragma unroll
                     for (int ml = 0; ml < MG; ++ml) {
                         const int m = m0 + wm * MFR * 16 + (pass * MG + ml) * 16 + fr;
-                        const int pos = min(m, (int)p.M - 1) % p.seq_len;
+                        const int pos = rope_row(p, m);
 #pragma unroll
                         for (int pr = 0; pr < NFH; ++pr) {
                             // rotary frequency of element 0: 32-column group of the packed 128-column head
@@ -805,7 +815,7 @@ __device__ __forceinline__ void finish_and_store(const GemmParams& p, int m, int
         if (n1 < p.rope_cols) {
             const int ch = n1 & 127;                       // column inside the packed head
             const int j = (ch >> 5) * 16 + (ch & 15);      // rotary frequency of element 0
-            const int pos = m % p.seq_len;
+            const int pos = rope_row(p, m);
             const f32x4 cs = *(const f32x4*)(p.rope_cos + (size_t)pos * 64 + j);
             const f32x4 sn = *(const f32x4*)(p.rope_sin + (size_t)pos * 64 + j);
 #pragma unroll
@@ -1389,6 +1399,14 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
                                int32_t ldc, int32_t epilogue, const void* aux, int32_t ldr, const float* rope_cos,
                                const float* rope_sin, int32_t seq_len, void* workspace, size_t workspace_bytes,
                                void* stream) {
+    return llada_gemm_bf16_positions(A, W, C, M, N, K, lda, ldc, epilogue, aux, ldr, rope_cos, rope_sin, seq_len, nullptr,
+                                     workspace, workspace_bytes, stream);
+}
+
+int llada_gemm_bf16_positions(const void* A, const void* W, void* C, int64_t M, int32_t N, int32_t K, int32_t lda,
+                              int32_t ldc, int32_t epilogue, const void* aux, int32_t ldr, const float* rope_cos,
+                              const float* rope_sin, int32_t seq_len, const int32_t* positions, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     LLADA_CHECK_ARG(A && W && C, "gemm: null operand");
     LLADA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
     LLADA_CHECK_SUPPORTED(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
@@ -1414,6 +1432,7 @@ extern "C" int llada_gemm_bf16(const void* A, const void* W, void* C, int64_t M,
     p.ldc = ldc;
     p.ldr = ldr;
     p.seq_len = seq_len;
+    p.positions = positions;
     p.slab = (float*)workspace;
     p.splits = 1;
     if (w_tiled || (g_w_tiled && N % BN == 0)) p.w_row_stride = BK;

@@ -116,7 +116,7 @@ __device__ __forceinline__ void store_rows48(const GemmParams& p, f32x4 (&acc)[3
                 }
             } else if constexpr (EPI == LLADA_EPI_ROPE_QKV) {
                 const int m = mrow0 + mf * 16 + fr;
-                const int pos = min(m, (int)p.M - 1) % p.seq_len;
+                const int pos = rope_row(p, m);
 #pragma unroll
                 for (int pr = 0; pr < NG; ++pr) {
                     const f32x4 x1 = acc[mf][2 * pr], x2 = acc[mf][2 * pr + 1];

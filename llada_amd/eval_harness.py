@@ -100,9 +100,10 @@ class LLaDAEvalHarness(_Base):
     def __init__(self, model_path='', mask_id=126336, max_length=4096, batch_size=32, mc_num=128,
                  is_check_greedy=True, cfg=0., steps=1024, gen_length=1024, block_length=1024,
                  remasking='low_confidence', device="cuda", *, model=None, tokenizer=None, process_group=None,
-                 seed=1234, rows_per_forward=32, **kwargs):
+                 seed=1234, rows_per_forward=32, generate_batch_size=1, pad_id=EOS_ID, **kwargs):
         """Keywords as eval_llada.py:33-48.  ``model=`` / ``tokenizer=`` take ready objects; otherwise
-        both are loaded from the local directory ``model_path``."""
+        both are loaded from the local directory ``model_path``.  ``generate_batch_size``: requests per
+        generate() call in generate_until (1 = one request at a time, as the reference runs them)."""
         if _Base is not object:
             super().__init__()
         self.device = torch.device(device)
@@ -133,6 +134,8 @@ class LLaDAEvalHarness(_Base):
         self.remasking = remasking
         self.seed = seed
         self.rows_per_forward = int(rows_per_forward)   # Monte-Carlo rows of several requests per forward
+        self.generate_batch_size = max(1, int(generate_batch_size))
+        self.pad_id = pad_id
         self._n_ll = 0
 
     @property
@@ -192,19 +195,57 @@ class LLaDAEvalHarness(_Base):
     def loglikelihood_rolling(self, requests):
         raise NotImplementedError                                                      # :243-244
 
+    def _finish_answer(self, answer_ids, until):
+        """eval_llada.py:267-275: decode, cut at the first stop sequence, strip special tokens."""
+        text = self.tokenizer.decode(answer_ids, skip_special_tokens=False)
+        text = trim_at_stops(text, until)
+        ids = self._ids(text)                                                          # :273-274: strip special tokens
+        return self.tokenizer.decode(ids, skip_special_tokens=True)
+
     def generate_until(self, requests):
-        """eval_llada.py:246-279: one request at a time (B = 1), temperature 0."""
-        out = []
-        for req in requests:
-            question, until = req.args[0], req.args[1]['until']
-            prompt = torch.tensor(self._ids(question), dtype=torch.long)[None, :].to(self.device)
-            generated = generate(self.model, prompt, steps=self.steps, gen_length=self.gen_length,
-                                 block_length=self.block_length, temperature=0, cfg_scale=self.cfg,
-                                 remasking=self.remasking, mask_id=self.mask_id)
-            text = self.tokenizer.decode(generated[0][prompt.shape[1]:].tolist(), skip_special_tokens=False)
-            text = trim_at_stops(text, until)
-            ids = self._ids(text)                                                      # :273-274: strip special tokens
-            out.append(self.tokenizer.decode(ids, skip_special_tokens=True))
+        """eval_llada.py:246-279.  The reference runs one request at a time (B = 1, temperature 0), and so does
+        this with ``generate_batch_size=1``.  With a larger value (llada_amd.LLaDAModel, cfg 0) requests share
+        generate() calls: prompts are left-padded to the longest of their group, the padding is masked as
+        attention keys and every row counts its rotary positions from its own first token
+        (generate(position_ids="from_mask")), so each row is computed as it is when it runs alone -- same
+        arithmetic, up to the rounding of a GEMM tiled for more rows.  Groups are formed in order of prompt
+        length (less padding); answers come back in request order."""
+        batched = (self.generate_batch_size > 1 and isinstance(self.model, LLaDAModel) and not self.cfg > 0.
+                   and len(requests) > 1)
+        if not batched:
+            out = []
+            for req in requests:
+                question, until = req.args[0], req.args[1]['until']
+                prompt = torch.tensor(self._ids(question), dtype=torch.long)[None, :].to(self.device)
+                generated = generate(self.model, prompt, steps=self.steps, gen_length=self.gen_length,
+                                     block_length=self.block_length, temperature=0, cfg_scale=self.cfg,
+                                     remasking=self.remasking, mask_id=self.mask_id)
+                out.append(self._finish_answer(generated[0][prompt.shape[1]:].tolist(), until))
+                if self._world_size > 1:
+                    torch.distributed.barrier(self.process_group)                      # :277
+            return out
+        prompts = [self._ids(req.args[0]) for req in requests]
+        order = sorted(range(len(requests)), key=lambda i: -len(prompts[i]))
+        out = [None] * len(requests)
+        for g0 in range(0, len(order), self.generate_batch_size):
+            group = order[g0:g0 + self.generate_batch_size]
+            P = max(len(prompts[i]) for i in group)
+            ids = torch.full((len(group), P), self.pad_id, dtype=torch.long)
+            mask = torch.zeros((len(group), P), dtype=torch.long)
+            for r, i in enumerate(group):
+                n = len(prompts[i])
+                if n:
+                    ids[r, P - n:] = torch.tensor(prompts[i], dtype=torch.long)
+                    mask[r, P - n:] = 1
+                else:
+                    mask[r, :] = 1            # an empty prompt has nothing to pad against
+            generated = generate(self.model, ids.to(self.device), mask.to(self.device), steps=self.steps,
+                                 gen_length=self.gen_length, block_length=self.block_length, temperature=0,
+                                 cfg_scale=self.cfg, remasking=self.remasking, mask_id=self.mask_id,
+                                 position_ids="from_mask")
+            rows = generated[:, P:].tolist()
+            for r, i in enumerate(group):
+                out[i] = self._finish_answer(rows[r], requests[i].args[1]['until'])
             if self._world_size > 1:
-                torch.distributed.barrier(self.process_group)                          # :277
+                torch.distributed.barrier(self.process_group)
         return out

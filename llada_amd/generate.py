@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .model import LLaDAModel, check_token_ids
+from .model import LLaDAModel, check_token_ids, positions_from_mask
 
 EOS_ID = 126081   # generate.py:95,101
 EOT_ID = 126348   # generate.py:101
@@ -55,7 +55,7 @@ def get_num_transfer_tokens(mask_index, steps):
 def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, block_length=128, temperature=0.,
              cfg_scale=0., remasking='low_confidence', mask_id=126336, logits_eos_inf=False,
              confidence_eos_eot_inf=False, *, seed=0, row_offset=0, noise_fn=None, rand_fn=None,
-             step_callback=None, cache=None):
+             step_callback=None, cache=None, position_ids=None):
     '''
     Args (generate.py:46-59):
         model: Mask predictor (llada_amd.LLaDAModel, or any object with .device and
@@ -76,6 +76,13 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
             other steps recompute only the block's positions against those cached keys and values of the
             rest of the sequence (prefix and suffix), which are then one block stale.  Only the block's own
             positions are transfer candidates in this mode (a mask token left of the block is ignored).
+        position_ids: None (default) rotates every token by its column index, as the reference's model does
+            whatever the padding.  "from_mask" (llada_amd.LLaDAModel only, needs ``attention_mask``) numbers
+            every row from its first attended token, so that a row of a LEFT-PADDED batch with its padding
+            masked is computed exactly as it is when it is run alone (up to the rounding of another GEMM
+            tiling): what lets a caller batch requests the reference runs one at a time
+            (eval_llada.py:260-265) and still get their batch-1 answers.  A [B, P + gen_length] integer
+            tensor gives the positions directly.
     '''
     lib = _lib.load()
     device = torch.device(model.device)
@@ -102,6 +109,21 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         raise NotImplementedError(f"cache={cache!r}")
     if cache is not None and not fast:
         raise NotImplementedError("cache='dual' needs an llada_amd.LLaDAModel")
+    pos = None
+    if position_ids is not None:
+        if not fast or cache is not None:
+            raise NotImplementedError("position_ids needs an llada_amd.LLaDAModel and cache=None")
+        if isinstance(position_ids, str):
+            if position_ids != "from_mask":
+                raise NotImplementedError(f"position_ids={position_ids!r}")
+            assert attention_mask is not None, "position_ids='from_mask' needs an attention_mask"
+            pos = positions_from_mask(attention_mask)
+        else:
+            pos = position_ids.to(device=device, dtype=torch.int32)
+            assert tuple(pos.shape) == (B, L)
+        if cfg_scale > 0.0:
+            pos = torch.cat([pos, pos], dim=0)
+        pos = pos.contiguous()
     kv = model.kv_cache(2 * B if cfg_scale > 0.0 else B, L) if cache == "dual" else None
     V = model.cfg.vocab_size if fast else None
     x0 = torch.empty_like(x)
@@ -145,7 +167,7 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                     if kv is not None and i > 0:
                         lg = model.forward_block(x_[:, bs:be], am2, L, bs, kv, out=logits_buf, update_cache=False)
                     else:
-                        lg = model.forward_rows(x_, am2, rows2, out=logits_buf, kv_cache=kv)
+                        lg = model.forward_rows(x_, am2, rows2, out=logits_buf, kv_cache=kv, position_ids=pos)
                     cond, un = lg[:n_rows], lg[n_rows:]
                     row_pos, nr = rows, n_rows
                 else:
@@ -159,7 +181,7 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                     cond = model.forward_block(x[:, bs:be], attention_mask, L, bs, kv, out=logits_buf, update_cache=False)
                     row_pos, nr = rows, n_rows
                 elif fast:
-                    cond = model.forward_rows(x, attention_mask, rows, out=logits_buf, kv_cache=kv)   # :92
+                    cond = model.forward_rows(x, attention_mask, rows, out=logits_buf, kv_cache=kv, position_ids=pos)   # :92
                     row_pos, nr = rows, n_rows
                 else:
                     lg = model(x, attention_mask=attention_mask).logits

@@ -33,6 +33,15 @@ def check_token_ids(ids, vocab_size, mask_id=None, what="input_ids"):
                          "(index out of range)")
 
 
+def positions_from_mask(attention_mask):
+    """Rotary positions that count from every row's first attended token: cumsum(mask) - 1, clamped at 0 on the
+    left padding.  With them (and the mask over the padding) a row of a left-padded batch is rotated exactly as it
+    is when it runs alone; the reference's model numbers by column whatever the padding (rotary attention depends
+    on position differences only, so the two agree up to rounding)."""
+    m = (attention_mask != 0).to(torch.int32)
+    return (torch.cumsum(m, dim=-1) - 1).clamp_(min=0).to(torch.int32)
+
+
 class LLaDAModel:
     def __init__(self, weights: LLaDAWeights):
         self.lib = _lib.load()
@@ -121,10 +130,11 @@ class LLaDAModel:
                                                 _lib.stream_ptr()))
         return out
 
-    def forward_rows(self, input_ids, attention_mask=None, logit_rows=None, out=None, kv_cache=None):
+    def forward_rows(self, input_ids, attention_mask=None, logit_rows=None, out=None, kv_cache=None, position_ids=None):
         """Forward on ids [n_seq, L]; returns bf16 logits [n_rows, V] for the flat token indices in
         ``logit_rows`` (int32 tensor) or for every token when it is None.  With ``kv_cache`` every layer's
-        [Q | K | V] image is left there for forward_block."""
+        [Q | K | V] image is left there for forward_block.  ``position_ids`` [n_seq, L] (int): the rotary position
+        of every token instead of its column index (see positions_from_mask); not together with ``kv_cache``."""
         assert input_ids.dim() == 2 and input_ids.dtype == torch.long
         ids = input_ids.to(self.device).contiguous()
         n_seq, L = ids.shape
@@ -139,7 +149,16 @@ class LLaDAModel:
         if out is None:
             out = torch.empty(n_rows, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
         ws = self._workspace(n_seq, L, n_rows)
-        if kv_cache is None:
+        if position_ids is not None:
+            if kv_cache is not None:
+                raise NotImplementedError("position_ids with a kv_cache")
+            pos = position_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            assert tuple(pos.shape) == (n_seq, L)
+            rc = self.lib.llada_forward_positions(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
+                                                  pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), n_seq, L,
+                                                  _lib.ptr(logit_rows), n_rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  _lib.stream_ptr())
+        elif kv_cache is None:
             rc = self.lib.llada_forward(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
                                         cos.data_ptr(), sin.data_ptr(), n_seq, L, _lib.ptr(logit_rows), n_rows,
                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
@@ -175,9 +194,9 @@ class LLaDAModel:
                                           _lib.stream_ptr()))
         return ws[:n_seq * L * c.d_model * 2].view(torch.bfloat16).view(n_seq, L, c.d_model).clone()
 
-    def __call__(self, input_ids, attention_mask=None):
+    def __call__(self, input_ids, attention_mask=None, position_ids=None):
         n_seq, L = input_ids.shape
-        logits = self.forward_rows(input_ids, attention_mask, None)
+        logits = self.forward_rows(input_ids, attention_mask, None, position_ids=position_ids)
         return ModelOutput(logits.view(n_seq, L, self.cfg.vocab_size))
 
     forward = __call__
