@@ -283,6 +283,41 @@ def other_configs(torch, generate, model, cfg, sync_all):
             sums = get_log_likelihood(model, p_ids, a_ids, **kw)
         sync_all()
         share[tag] = {"ms_per_call": round(1e3 * (time.perf_counter() - t0) / 3, 2), "loss_sums": [round(float(v), 3) for v in sums.cpu()]}
+    # the evaluation harness' generate_until (eval_llada.py:246-279) on 8 requests of different prompt lengths: one request
+    # at a time, as the reference runs them, against one left-padded batch with masked padding and per-row positions
+    from llada_amd.eval_harness import LLaDAEvalHarness
+
+    class _IdTokenizer:
+        """Tokens are written as decimal ids separated by blanks (a benchmark needs no vocabulary)."""
+
+        def __call__(self, text):
+            return {"input_ids": [int(t) for t in text.split()]}
+
+        def decode(self, ids, skip_special_tokens=False):
+            return " ".join(str(int(i)) for i in ids if not (skip_special_tokens and int(i) >= 126000))
+
+    class _Req:
+        def __init__(self, *args):
+            self.args = args
+    lens = [128, 96, 120, 64, 100, 128, 80, 112]
+    reqs = [_Req(" ".join(str(int(v)) for v in prompts[i, :n]), {"until": ["<|never|>"]}) for i, n in enumerate(lens)]
+    hk = dict(model=model, tokenizer=_IdTokenizer(), steps=64, gen_length=64, block_length=32, mc_num=1, batch_size=1)
+    hres = {}
+    for tag, nb in (("one_request_at_a_time", 1), ("batched_8", 8)):
+        h = LLaDAEvalHarness(generate_batch_size=nb, **hk)
+        h.generate_until(reqs[:2])
+        sync_all()
+        t0 = time.perf_counter()
+        texts = h.generate_until(reqs)
+        sync_all()
+        dt = time.perf_counter() - t0
+        hres[tag] = {"requests_per_s": round(len(reqs) / dt, 3), "tokens_per_s": round(len(reqs) * 64 / dt, 1), "seconds": round(dt, 3)}
+        hres.setdefault("_texts", []).append(texts)
+    a, b = hres.pop("_texts")
+    ta, tb = " ".join(a).split(), " ".join(b).split()
+    hres["answer_tokens_identical"] = round(sum(x == y for x, y in zip(ta, tb)) / max(len(ta), 1), 4)
+    hres["workload"] = "LLaDAEvalHarness.generate_until: 8 requests, prompts of 64-128 tokens, gen_length=64, steps=64, block_length=32"
+    out["harness_generate_until"] = hres
     share["workload"] = "rank 3 of 8 of the call above (4 rows x 4 iterations x 384 tokens), alone on one GPU"
     out["likelihood_mc128_bs32_one_rank_of_8"] = share
     return out

@@ -605,3 +605,33 @@ def test_embed(lib):
     check(lib, lib.llada_embed_bf16(wt.data_ptr(), it.data_ptr(), out.data_ptr(), n, d, V, stream()))
     torch.cuda.synchronize()
     assert np.array_equal(host(out), wte[ids])
+
+
+def test_gemm_rope_epilogue_with_explicit_positions(lib):
+    """llada_forward_positions rotates token m with row positions[m] of the rotary tables.  On a one-layer model:
+    explicit positions equal to the column index reproduce the default numbering bit for bit; a sequence that sits
+    behind 5 masked padding columns and is numbered from its own first token (positions_from_mask) gives the logits
+    of the bare sequence to bf16 noise, as does numbering by column (rotary attention depends on position
+    differences only); positions outside the tables are clamped, never read out of bounds."""
+    import torch
+    from llada_amd import LLaDAConfig, LLaDAModel, LLaDAWeights
+    from llada_amd.model import positions_from_mask
+    cfg = LLaDAConfig(d_model=256, n_layers=1, n_heads=2, mlp_hidden=512, vocab_size=512)
+    model = LLaDAModel(LLaDAWeights.random(cfg, "cuda", seed=5, std=0.05, head_scale=4.0))
+    g = torch.Generator().manual_seed(1)
+    n, pad = 40, 5
+    row = torch.randint(0, 500, (1, n), generator=g)
+    ids = torch.cat([torch.full((1, pad), 9, dtype=torch.long), row], dim=1).cuda()
+    mask = torch.cat([torch.zeros(1, pad, dtype=torch.long), torch.ones(1, n, dtype=torch.long)], dim=1).cuda()
+    alone = model(row.cuda()).logits.float()[0]
+    with_pos = model(ids, mask, position_ids=positions_from_mask(mask)).logits.float()[0, pad:]
+    by_col = model(ids, mask).logits.float()[0, pad:]
+    # explicit positions equal to the column index are the default numbering, bit for bit
+    cols = torch.arange(pad + n, dtype=torch.int32)[None, :].cuda()
+    assert torch.equal(model(ids, mask, position_ids=cols).logits, model(ids, mask).logits)
+    scale = alone.abs().max()
+    assert (with_pos - alone).abs().max() <= 2e-2 * scale
+    assert (by_col - alone).abs().max() <= 2e-2 * scale
+    # out-of-table positions are clamped, not read out of bounds
+    wild = torch.full((1, pad + n), 10 ** 6, dtype=torch.int32).cuda()
+    assert torch.isfinite(model(ids, mask, position_ids=wild).logits.float()).all()
