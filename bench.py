@@ -542,11 +542,18 @@ def main():
         flops_step = 2.0 * M * lin + 2.0 * R * (d * d + 3 * d * F) + 2.0 * R * d * V + M * 4.0 * L * d * cfg.n_layers
         # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes (counters
         # cannot be read from inside the process); the committed record is quoted, null without it
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_gateup_traffic.json")
+        traffic, traffic_source = None, None
+        pmc_name = "r3_pmc_gateup_traffic.json"
+        pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if B * L == 3072 and os.path.exists(pmc_file):
             with open(pmc_file) as fh:
-                traffic = json.load(fh).get("traffic_bytes")
+                pmc = json.load(fh)
+            traffic = pmc.get("traffic_bytes")
+            traffic_source = {"file": "profiles/" + pmc_name, "date": pmc.get("date"), "command": pmc.get("command"),
+                              "read_bytes": pmc.get("read_bytes"), "write_bytes": pmc.get("write_bytes"),
+                              "algorithmic_bytes": pmc.get("algorithmic_bytes"),
+                              "note": "separate rocprofv3 --pmc passes on the same kernel and shape (counters cannot be read from "
+                                      "inside the timed process); memory-side requests of the L2s, Infinity-Cache hits included"}
         rec = {
             "metric": f"generated tokens/sec/node, LLaDA-8B gen{G} steps{steps_total} blk{bl}; ms/denoise step",
             "value": round(tokens_per_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": K_, "warmup": W_,
@@ -566,7 +573,7 @@ def main():
             "mfma_util_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_stream_kernel<6,SWIGLU> (gate/up projection, M = rows_per_gpu x seq_len)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "launches_timed": n_s.value, "avg_launch_ms": round(gemm_ms, 4),
                          "flops_per_launch": gemm_flops},
         }

@@ -26,9 +26,6 @@ constexpr int EPI_PARTIAL = 100;   // internal: float32 partial tile of a split-
 #ifndef LLADA_GEMM_DEBUG
 #define LLADA_GEMM_DEBUG 0
 #endif
-#ifndef LLADA_GEMM_W_NT_128
-#define LLADA_GEMM_W_NT_128 1
-#endif
 
 struct GemmParams {
     const bf16_t* A;
@@ -386,7 +383,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_kernel(const GemmParams
 // region is refilled only after the barrier that follows its last read.
 // The vmcnt counts assume every phase issues its region, so past the last K tile the phases keep
 // issuing loads (of tile nk-1, into regions nobody reads again).
-template <int MFR, int EPI, int NFH = 2, int WNT = -1>
+template <int MFR, int EPI, int NFH = 2, int WNT = 0>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = MFR * 32;
@@ -410,10 +407,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     // plus 8 half pieces (4 rows, lanes 0-31 of a second instruction issued with EXEC[63:32] = 0).
     constexpr bool two_a = A_GROUPS > 8;
     constexpr bool half_a = A_GROUPS == 12;
-    // Non-temporal weight DMA where every weight line is read by one to three workgroups (small M): the 128-row and
-    // 128-column tiles only run there; the host asks for it explicitly (WNT = 1) when it plans a small-M launch on
-    // the 192 x 256 tile.  An HBM stream by LDS-DMA reads 6.9-7.0 TB/s with it against 5.9 TB/s without.
-    constexpr bool W_NT = WNT < 0 ? (LLADA_GEMM_W_NT_128 && (MFR == 4 || NFH == 1)) : (WNT != 0);
+    // Non-temporal weight DMA (WNT = 1): a launch decision of the host, taken when M is so small that a weight
+    // line is read by a handful of workgroups at most (weights_stream_once).  An HBM stream by LDS-DMA reads
+    // 6.9-7.0 TB/s with it against 5.9 TB/s without; where ten or more workgroups share a line through the L2 it
+    // would throw that reuse away.
+    constexpr bool W_NT = WNT != 0;
 
     int tm, tn;
     tile_of_block(blockIdx.x % p.n_tiles, p.n_tiles, p.tiles_m, p.tiles_n, tm, tn, p.band_m, p.remap);
@@ -1007,7 +1005,7 @@ int pick_splits(int nt, int nk_total, int64_t M, int N, bool pipelined_ok) {
     return best;
 }
 
-template <int MFR, int EPI, int NFH = 2, int WNT = -1>
+template <int MFR, int EPI, int NFH = 2, int WNT = 0>
 int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     constexpr int BM = MFR * 32;
     constexpr int lds = 2 * (BM + 128 * NFH) * ROW_BYTES;
@@ -1015,14 +1013,14 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     if constexpr (NFH == 1) {   // 128-column tile: the pipelined loop only (the caller checked nk >= 4 and even)
         static OncePerDevice attr4_set;
         if (attr4_set.first()) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI, 1>,
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pipelined_kernel<MFR, EPI, 1, WNT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) {
                 llada_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
                 return LLADA_ERR_HIP;
             }
         }
-        hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI, 1>), dim3(grid), dim3(NTHREADS), lds, stream, q);
+        hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI, 1, WNT>), dim3(grid), dim3(NTHREADS), lds, stream, q);
         LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
         return LLADA_OK;
     } else {
@@ -1030,8 +1028,8 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
         // The persistent form pays off where a workgroup gets several tiles and the write-out issues no
         // loads of its own (gate/up projection: 6 tiles per CU at M = 3072); elsewhere it is neutral or
         // slower in situ.  Hook values: 2 = always, 3 = never.
-        const bool stream_ok = g_use_pipelined == 2 ||
-                               (g_use_pipelined == 1 && EPI == LLADA_EPI_SWIGLU && grid >= 2 * g_stream_grid);
+        const bool stream_ok = WNT == 0 && (g_use_pipelined == 2 ||
+                                            (g_use_pipelined == 1 && EPI == LLADA_EPI_SWIGLU && grid >= 2 * g_stream_grid));
         if (stream_ok && nk >= 4 && (nk & 1) == 0) {
             constexpr int stream_lds = lds + 8 * 2 * 16 * 144;   // + the write-out slices (2 m-fragments per wave)
             static OncePerDevice attr3_set;
@@ -1080,15 +1078,29 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
     }
 }
 
+// Non-temporal weight DMA is worth it where (almost) nobody re-reads a weight line: at most three 192-row tile
+// rows, i.e. one sequence of up to 576 tokens or the pruned last layer.  The 256-row tile never runs there.
+template <int MFR, int EPI, int NFH>
+int launch_main_nt(const GemmParams& q, int grid, hipStream_t stream) {
+    if constexpr (MFR == 8) {
+        return launch_main<MFR, EPI, NFH, 0>(q, grid, stream);
+    } else {
+        const bool weights_stream_once = g_use_pipelined == 1 && q.M <= 3 * 192;
+        return weights_stream_once ? launch_main<MFR, EPI, NFH, 1>(q, grid, stream) : launch_main<MFR, EPI, NFH, 0>(q, grid, stream);
+    }
+}
+
 int g_no_store = 0;       // diagnostic hook
 int g_force_cols = 0;     // test hook: 128 / 256 forces the N tile, 0 = automatic
 int g_force_small_m = 0;  // test hook: > 0 runs the loop of gemm_small_m.h with 32 * value tile columns (never chosen automatically:
                           // inside a denoising step it is 1-2 % slower than the plans below, see the header)
 
-// ---- launch plans for small M (one or two sequences) ---------------------------------------------------------
+// ---- launch plans for under-filled launches ------------------------------------------------------------------
 // At M = 384 the 256-column tile gives 96-192 work items for 256 CUs, so the tile height, the tile width (the
-// pipelined loop also runs 128 columns wide) and the split count are chosen together from a cost model fitted to
-// measured launches of the four LLaDA-8B projections at M = 384 (weights cold): microseconds =
+// pipelined loop also runs 128 columns wide) and the split count are chosen together.  The planner runs for every
+// launch the legacy plan leaves under 192 tiles (one or two sequences, the pruned last layer, and the N = 4096
+// projections up to M ~ 2000); its cost model is fitted to measured launches of the four LLaDA-8B projections at
+// M = 384 (weights cold) and is extrapolated, not re-fitted, above that: microseconds =
 // rounds * (8 + t_step * K steps) + second pass of a split (4 + slab bytes / 3 TB/s), with t_step per
 // (tile rows, tile columns).  Model against measurement: QKV 192 x 128 unsplit 49.6 (49.6), 128 x 256 unsplit 56.6
 // (58.1); attention output 192 x 128 in 4 ranges 30.8 (27.1); MLP output 192 x 256 in 8 ranges 50.4 (49.8).
@@ -1264,22 +1276,14 @@ int launch(const GemmParams& p, hipStream_t stream) {
             q.tiles_n = p.N / 128;
             q.n_tiles = q.tiles_m * q.tiles_n;
             q.splits = narrow;
-            if (narrow == 1) return launch_main<MFR, EPI, 1>(q, q.n_tiles, stream);
-            const int rc = launch_main<MFR, EPI_PARTIAL, 1>(q, q.n_tiles * narrow, stream);
+            if (narrow == 1) return launch_main_nt<MFR, EPI, 1>(q, q.n_tiles, stream);
+            const int rc = launch_main_nt<MFR, EPI_PARTIAL, 1>(q, q.n_tiles * narrow, stream);
             if (rc != LLADA_OK) return rc;
             return finish_split<EPI>(q, stream);
         }
     }
-    if constexpr (MFR == 6) {     // a planned small-M launch on the 192 x 256 tile: the same loop, weights non-temporal
-        if (p.plan_nfh == 2 && g_use_pipelined == 1 && p.M <= 3 * 192) {   // at most three workgroups read a weight line
-            if (q.splits == 1) return launch_main<MFR, EPI, 2, 1>(q, q.n_tiles, stream);
-            const int rc = launch_main<MFR, EPI_PARTIAL, 2, 1>(q, q.n_tiles * q.splits, stream);
-            if (rc != LLADA_OK) return rc;
-            return finish_split<EPI>(q, stream);
-        }
-    }
-    if (q.splits == 1) return launch_main<MFR, EPI>(q, q.n_tiles, stream);
-    const int rc = launch_main<MFR, EPI_PARTIAL>(q, q.n_tiles * q.splits, stream);
+    if (q.splits == 1) return launch_main_nt<MFR, EPI, 2>(q, q.n_tiles, stream);
+    const int rc = launch_main_nt<MFR, EPI_PARTIAL, 2>(q, q.n_tiles * q.splits, stream);
     if (rc != LLADA_OK) return rc;
     return finish_split<EPI>(q, stream);
 }
