@@ -312,10 +312,7 @@ def other_configs(torch, generate, model, cfg, sync_all):
         sync_all()
         dt = time.perf_counter() - t0
         hres[tag] = {"requests_per_s": round(len(reqs) / dt, 3), "tokens_per_s": round(len(reqs) * 64 / dt, 1), "seconds": round(dt, 3)}
-        hres.setdefault("_texts", []).append(texts)
-    a, b = hres.pop("_texts")
-    ta, tb = " ".join(a).split(), " ".join(b).split()
-    hres["answer_tokens_identical"] = round(sum(x == y for x, y in zip(ta, tb)) / max(len(ta), 1), 4)
+        assert len(texts) == len(reqs)
     hres["workload"] = "LLaDAEvalHarness.generate_until: 8 requests, prompts of 64-128 tokens, gen_length=64, steps=64, block_length=32"
     out["harness_generate_until"] = hres
     share["workload"] = "rank 3 of 8 of the call above (4 rows x 4 iterations x 384 tokens), alone on one GPU"

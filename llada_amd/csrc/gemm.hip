@@ -1293,7 +1293,8 @@ int launch(const GemmParams& p, hipStream_t stream) {
 // (a tile needs its full latency; measured ~0.8 of one).  Factors from measurements at K = 4096: the 256-row
 // pipelined loop moves 14 % fewer operand bytes per FLOP and runs ~4 % faster per row than the 192-row one
 // when its tile count fills the rounds (M = 5120: QKV 353 vs 411 us, gate/up 705 vs 759 us); the 128-row
-// loop is ~3 % slower per row.
+// loop is 10-17 % slower per row (M = 2304 and 1536, whole rounds: 0.392-0.405 us per row and round against
+// 0.345-0.359 for the 192-row tile).
 int pick_mfr(int64_t M, int N, int K) {
     (void)K;
     const int cands[3] = {8, 6, 4};
@@ -1305,7 +1306,7 @@ int pick_mfr(int64_t M, int N, int K) {
         const int64_t tiles_m = (M + bm - 1) / bm;
         const int64_t nt = tiles_m * tiles_n;
         const double rounds = (double)(nt / 256) + ((nt % 256) ? 0.8 : 0.0);
-        const double cost = rounds * bm * (c == 8 ? 0.96 : (c == 6 ? 1.0 : 1.03));
+        const double cost = rounds * bm * (c == 8 ? 0.96 : (c == 6 ? 1.0 : 1.12));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
