@@ -57,9 +57,13 @@ def main():
 
     device = torch.device(args.device)
     torch.cuda.set_device(device)
+    import glob
+    if not glob.glob(os.path.join(args.checkpoint, "*.safetensors")):
+        sys.exit(f"{args.checkpoint} holds no *.safetensors files: both sides load tensors only (a pytorch_model*.bin "
+                 "would be unpickled by transformers; convert the checkpoint first)")
     tok = AutoTokenizer.from_pretrained(args.checkpoint, trust_remote_code=True, local_files_only=True)
     ref_model = AutoModel.from_pretrained(args.checkpoint, trust_remote_code=True, torch_dtype=torch.bfloat16,
-                                          local_files_only=True).to(device).eval()
+                                          local_files_only=True, use_safetensors=True).to(device).eval()
     model = LLaDAModel(LLaDAWeights.from_checkpoint(args.checkpoint, device))
     mask_id = model.cfg.mask_token_id
     G, bl = args.gen_length, args.block_length
