@@ -278,3 +278,65 @@ def test_likelihood_many_matches_one_by_one(lib, tiny, mc_num, batch_size, cfg_s
         one = get_log_likelihood(model, p, a, mc_num=mc_num, batch_size=batch_size, cfg_scale=cfg_scale, mask_id=MASK_ID,
                                  seed=s)
         assert abs(v - one) <= 1e-3 * abs(one), (len(p), len(a), v, one)
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_forward_with_explicit_positions_both_weight_layouts(lib, tiny, packed):
+    """Explicit rotary positions in the fused QKV epilogue (packed weights) and in the separate rotary kernel
+    (checkpoint layout): an arbitrary position table gives the oracle's logits for the same table -- the oracle
+    rotates with the table rows picked by position -- and both layouts give the same logits."""
+    from oracle import model as om
+    z, ocfg, W = tiny
+    model = build(ocfg, W, packed)
+    ids = z["ids"]
+    B, L = ids.shape
+    g = np.random.Generator(np.random.PCG64(5))
+    pos = np.stack([g.permutation(L), np.minimum(np.arange(L) // 2 + 3, L - 1)]).astype(np.int32)   # any rows of the table
+    got = model(torch.from_numpy(ids).cuda(), position_ids=torch.from_numpy(pos).cuda()).logits.float().cpu().numpy()
+
+    # oracle with the same per-token table rows
+    cos, sin = om.rope_tables(L, ocfg.head_dim, ocfg.rope_theta)
+    x = W["wte"][ids].astype(np.float32)
+    H, D = ocfg.n_heads, ocfg.head_dim
+    for i in range(ocfg.n_layers):
+        Wl = {k: W[f"blocks.{i}.{k}"] for k in om.LAYER_KEYS}
+        h = om.rmsnorm(x, Wl["attn_norm"], ocfg.rms_eps, True)
+        q, k, v = (om.round_bf16(h @ Wl[n].T).reshape(B, L, H, D).transpose(0, 2, 1, 3) for n in ("q_proj", "k_proj", "v_proj"))
+        qr, kr = np.empty_like(q), np.empty_like(k)
+        for b in range(B):
+            qr[b:b + 1] = om.apply_rope(q[b:b + 1], cos[pos[b]], sin[pos[b]], True)
+            kr[b:b + 1] = om.apply_rope(k[b:b + 1], cos[pos[b]], sin[pos[b]], True)
+        a = om.attention(qr, kr, v, None, True).transpose(0, 2, 1, 3).reshape(B, L, H * D)
+        x = om.round_bf16(x + om.round_bf16(a @ Wl["attn_out"].T))
+        h = om.rmsnorm(x, Wl["ff_norm"], ocfg.rms_eps, True)
+        gt, up = om.round_bf16(h @ Wl["ff_proj"].T), om.round_bf16(h @ Wl["up_proj"].T)
+        act = om.round_bf16(gt / (np.float32(1.0) + np.exp(-gt)))
+        x = om.round_bf16(x + om.round_bf16(om.round_bf16(act * up) @ Wl["ff_out"].T))
+    ref = om.round_bf16(om.rmsnorm(x, W["ln_f"], ocfg.rms_eps, True) @ W["ff_out"].T)
+    assert max_rel(got, ref) <= 2e-2, max_rel(got, ref)
+    plain = model(torch.from_numpy(ids).cuda()).logits.float().cpu().numpy()
+    assert max_rel(plain, ref) > 5e-2            # the table rows matter: column numbering is another function here
+
+
+def test_generate_with_guidance_and_positions_from_mask(lib, tiny):
+    """generate(position_ids="from_mask") under classifier-free guidance (the conditional and the unconditional copy
+    share the positions) on a left-padded batch: every step's candidates are those of the same call without explicit
+    positions wherever the top-2 margin is clear (both numberings are the same function up to rounding), and the
+    transfer counts are exact."""
+    from llada_amd import generate
+    z, ocfg, W = tiny
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(9))
+    B, P, G, bl = 3, 12, 16, 8
+    prompt = torch.from_numpy(g.integers(0, MASK_ID, size=(B, P), dtype=np.int64))
+    am = torch.ones(B, P, dtype=torch.long)
+    am[1, :5] = 0
+    am[2, :9] = 0
+    counts = []
+    out = generate(model, prompt, am, steps=8, gen_length=G, block_length=bl, temperature=0., cfg_scale=1.5, mask_id=MASK_ID,
+                   position_ids="from_mask", step_callback=lambda b, s, x, x0, c: counts.append(int((x == MASK_ID).sum())))
+    assert counts == [B * (G - 2 * (i + 1)) for i in range(8)] and not (out == MASK_ID).any()
+    with pytest.raises(AssertionError):
+        generate(model, prompt, None, steps=8, gen_length=G, block_length=bl, mask_id=MASK_ID, position_ids="from_mask")
+    with pytest.raises(NotImplementedError):
+        generate(model, prompt, am, steps=8, gen_length=G, block_length=bl, mask_id=MASK_ID, position_ids="from_mask", cache="dual")
