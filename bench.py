@@ -607,21 +607,25 @@ def main():
                                                   "weight_bytes_per_step": w_bytes}}
         if world == 1 and not args.no_latency:
             # opt-in approximation outside the reference (cache="dual"): whole generate() calls, wall clock
-            def whole_call(p_):
-                generate(model, p_, None, steps=G, gen_length=G, block_length=bl, cache="dual")
+            def whole_call(p_, kind="dual"):
+                generate(model, p_, None, steps=G, gen_length=G, block_length=bl, cache=kind)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                generate(model, p_, None, steps=G, gen_length=G, block_length=bl, cache="dual")
+                generate(model, p_, None, steps=G, gen_length=G, block_length=bl, cache=kind)
                 torch.cuda.synchronize()
                 return time.perf_counter() - t0
             tc = whole_call(prompt)
-            rec["block_cached"] = {"note": "generate(cache='dual'): APPROXIMATION, not the reference's algorithm; never `value`",
+            rec["block_cached"] = {"note": "generate(cache='dual' | 'prefix'): APPROXIMATIONS, not the reference's algorithm; never `value`",
                                    "tokens_per_s": round(B * G / tc, 1), "ms_per_step_mean": round(1e3 * tc / steps_total, 3),
                                    "seconds_per_call": round(tc, 3)}
+            tp = whole_call(prompt, "prefix")
+            rec["block_cached"]["prefix_tokens_per_s"] = round(B * G / tp, 1)
+            rec["block_cached"]["prefix_ms_per_step_mean"] = round(1e3 * tp / steps_total, 3)
             if B != 1:
                 t1c = whole_call(prompt[:1])
                 rec["block_cached"]["batch1_tokens_per_s"] = round(G / t1c, 1)
                 rec["block_cached"]["batch1_ms_per_step_mean"] = round(1e3 * t1c / steps_total, 3)
+                rec["block_cached"]["batch1_prefix_tokens_per_s"] = round(G / whole_call(prompt[:1], "prefix"), 1)
         if world == 1 and not strong and B == 8 and (P, G, bl) == (128, 256, 32) and not args.no_latency:
             rec["other_configs"] = other_configs(torch, generate, model, cfg, sync_all)
         if world == 1 and not args.no_cpu_baseline:      # the host baseline is reported at N = 1 only

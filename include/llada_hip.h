@@ -210,8 +210,11 @@ size_t llada_attn_workspace_bytes(int32_t n_seq, int32_t n_q, int32_t seq_len, i
  * ([n_layers][n_seq*seq_len][3*d] bf16, llada_kv_cache_bytes) in kv_cache; llada_forward_block then
  * recomputes only the block_len positions from block_start of every sequence (block_ids
  * [n_seq, block_len]): their keys/values replace the cached ones, their queries attend over the whole
- * cached sequence, and logits_out [n_seq*block_len, vocab] holds their logits.  Keys and values of the
- * other positions stay as they were when the cache was filled.  update_cache == 0 leaves the cache untouched
+ * cached sequence, and logits_out [n_seq*block_len, vocab] holds their logits -- or, with logit_rows
+ * ([n_logit_rows] int32 indices into the n_seq*block_len recomputed rows, seq * block_len + offset), only the
+ * logits of those rows, logits_out [n_logit_rows, vocab].  Keys and values of the
+ * other positions stay as they were when the cache was filled.  The range may reach to the end of the sequence
+ * (block_start + block_len == seq_len: everything right of a cached prefix is recomputed).  update_cache == 0 leaves the cache untouched
  * (the block's fresh keys/values are used for this call only: enough when the next call for another block is
  * preceded by a new llada_forward_fill_cache, as in generate()); the logits are the same either way.
  * ------------------------------------------------------------------------------------------- */
@@ -224,7 +227,8 @@ size_t llada_forward_block_workspace_bytes(const llada_config* cfg, int32_t n_se
 int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
                         const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                         int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache, int32_t update_cache,
-                        void* logits_out, void* workspace, size_t workspace_bytes, void* stream);
+                        const int32_t* logit_rows, int32_t n_logit_rows, void* logits_out, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sampler epilogue: replaces generate.py:81-134 after the forward.

@@ -72,7 +72,7 @@ SIGNATURES = {
                                            C.c_int32, vp, vp, C.c_size_t, vp, vp]),
     "llada_forward_block_workspace_bytes": (C.c_size_t, [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32]),
     "llada_forward_block": (C.c_int, [C.POINTER(Config), C.POINTER(Weights), vp, vp, vp, vp, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, C.c_size_t, vp]),
+                                      C.c_int32, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp, C.c_size_t, vp]),
     "llada_num_transfer_tokens": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                             vp, vp]),
     "llada_add_gumbel_noise": (C.c_int, [vp, vp, C.c_double, vp, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,

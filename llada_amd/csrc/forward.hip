@@ -228,10 +228,11 @@ int forward_impl(const llada_config* cfg, const llada_weights* w, const int64_t*
 extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights* w, const int64_t* block_ids,
                                    const uint8_t* key_mask, const float* rope_cos, const float* rope_sin, int32_t n_seq,
                                    int32_t seq_len, int32_t block_start, int32_t block_len, void* kv_cache,
-                                   int32_t update_cache, void* logits_out, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+                                   int32_t update_cache, const int32_t* logit_rows, int32_t n_logit_rows,
+                                   void* logits_out, void* workspace, size_t workspace_bytes, void* stream) {
     LLADA_CHECK_ARG(cfg && w && block_ids && rope_cos && rope_sin && logits_out && workspace && kv_cache,
                     "forward_block: null argument");
+    LLADA_CHECK_ARG(logit_rows == nullptr || n_logit_rows > 0, "forward_block: logit_rows without a count");
     LLADA_CHECK_ARG(n_seq > 0 && seq_len > 0 && block_len > 0 && block_start >= 0 && block_start + block_len <= seq_len,
                     "forward_block: bad shape");
     const llada_config& c = *cfg;
@@ -300,6 +301,12 @@ extern "C" int llada_forward_block(const llada_config* cfg, const llada_weights*
                                              c.rms_eps, Mb, d, F, F, tl, sk, skb, stream));
     }
     if (c.n_layers == 0) TRY(llada_rmsnorm_bf16(x, w->ln_f, hf, Mb, d, c.rms_eps, nullptr, stream));
+    if (logit_rows) {   // LM head on the wanted rows only: their normalised rows are compacted into h (free by now)
+        TRY(llada_gather_rows_bf16(hf, logit_rows, h, n_logit_rows, d, Mb, stream));
+        TRY(llada_gemm_bf16(h, w->lm_head, logits_out, n_logit_rows, V, d, d, V, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr,
+                            nullptr, 0, sk, skb, stream));
+        return LLADA_OK;
+    }
     TRY(llada_gemm_bf16(hf, w->lm_head, logits_out, Mb, V, d, d, V, LLADA_EPI_PLAIN | tf, nullptr, 0, nullptr, nullptr, 0, sk,
                         skb, stream));
     return LLADA_OK;

@@ -76,6 +76,10 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
             other steps recompute only the block's positions against those cached keys and values of the
             rest of the sequence (prefix and suffix), which are then one block stale.  Only the block's own
             positions are transfer candidates in this mode (a mask token left of the block is ignored).
+            "prefix" is the milder APPROXIMATION of the same family: only the keys and values LEFT of the block
+            (prompt and finished blocks) are cached at the block's first step; the block's other steps recompute
+            the block and everything right of it.  Slower than "dual", closer to the reference (the still-masked
+            suffix is never stale).
         position_ids: None (default) rotates every token by its column index, as the reference's model does
             whatever the padding.  "from_mask" (llada_amd.LLaDAModel only, needs ``attention_mask``) numbers
             every row from its first attended token, so that a row of a LEFT-PADDED batch with its padding
@@ -105,10 +109,10 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
     fast = isinstance(model, LLaDAModel)
     if fast:
         check_token_ids(prompt, model.cfg.vocab_size, mask_id, "prompt")   # the reference's embedding would raise
-    if cache not in (None, "dual"):
+    if cache not in (None, "dual", "prefix"):
         raise NotImplementedError(f"cache={cache!r}")
     if cache is not None and not fast:
-        raise NotImplementedError("cache='dual' needs an llada_amd.LLaDAModel")
+        raise NotImplementedError(f"cache={cache!r} needs an llada_amd.LLaDAModel")
     pos = None
     if position_ids is not None:
         if not fast or cache is not None:
@@ -124,7 +128,7 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         if cfg_scale > 0.0:
             pos = torch.cat([pos, pos], dim=0)
         pos = pos.contiguous()
-    kv = model.kv_cache(2 * B if cfg_scale > 0.0 else B, L) if cache == "dual" else None
+    kv = model.kv_cache(2 * B if cfg_scale > 0.0 else B, L) if cache is not None else None
     V = model.cfg.vocab_size if fast else None
     x0 = torch.empty_like(x)
     conf = torch.empty((B, L), dtype=torch.float32, device=device)
@@ -155,6 +159,14 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
         rows = (batch_idx + torch.arange(row_lo, be, device=device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
         n_rows = rows.numel()
         rows2 = torch.cat([rows, rows + B * L]).contiguous() if cfg_scale > 0.0 else None
+        # cached steps recompute [bs, ce) of every sequence: the block ("dual") or everything from the block on
+        # ("prefix"); logits are asked for the block's positions only
+        ce = be if cache == "dual" else L
+        crows = None
+        if cache == "prefix":
+            nb_ = 2 * B if cfg_scale > 0.0 else B
+            crows = (torch.arange(nb_, device=device, dtype=torch.int32)[:, None] * (ce - bs)
+                     + torch.arange(0, be - bs, device=device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
         logits_buf = None
         if fast:
             logits_buf = torch.empty((2 * n_rows if cfg_scale > 0.0 else n_rows, V), dtype=torch.bfloat16, device=device)
@@ -165,7 +177,8 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                 x_ = torch.cat([x, un_x], dim=0)
                 if fast:
                     if kv is not None and i > 0:
-                        lg = model.forward_block(x_[:, bs:be], am2, L, bs, kv, out=logits_buf, update_cache=False)
+                        lg = model.forward_block(x_[:, bs:ce], am2, L, bs, kv, out=logits_buf, update_cache=False,
+                                                 logit_rows=crows)
                     else:
                         lg = model.forward_rows(x_, am2, rows2, out=logits_buf, kv_cache=kv, position_ids=pos)
                     cond, un = lg[:n_rows], lg[n_rows:]
@@ -178,7 +191,8 @@ def generate(model, prompt, attention_mask=None, steps=128, gen_length=128, bloc
                 un_ptr = un.data_ptr()
             else:
                 if fast and kv is not None and i > 0:
-                    cond = model.forward_block(x[:, bs:be], attention_mask, L, bs, kv, out=logits_buf, update_cache=False)
+                    cond = model.forward_block(x[:, bs:ce], attention_mask, L, bs, kv, out=logits_buf, update_cache=False,
+                                               logit_rows=crows)
                     row_pos, nr = rows, n_rows
                 elif fast:
                     cond = model.forward_rows(x, attention_mask, rows, out=logits_buf, kv_cache=kv, position_ids=pos)   # :92

@@ -105,12 +105,14 @@ class LLaDAModel:
         need = self.lib.llada_kv_cache_bytes(C.byref(self._c_cfg), n_seq, L)
         return torch.empty(need, dtype=torch.uint8, device=self.device)
 
-    def forward_block(self, block_ids, attention_mask, seq_len, block_start, kv_cache, out=None, update_cache=True):
+    def forward_block(self, block_ids, attention_mask, seq_len, block_start, kv_cache, out=None, update_cache=True,
+                      logit_rows=None):
         """Recompute only the positions [block_start, block_start + block_len) of every sequence
         (block_ids [n_seq, block_len]) against ``kv_cache`` (filled by forward_rows(..., kv_cache=)): their
         keys and values replace the cached ones (``update_cache=False``: they are used for this call only and
         the cache stays as it is; same logits).  ``attention_mask`` is the full [n_seq, seq_len] mask.
-        Returns bf16 logits [n_seq * block_len, V]."""
+        Returns bf16 logits [n_seq * block_len, V], or [n_rows, V] for the rows ``logit_rows`` (int32 indices
+        seq * block_len + offset into the recomputed rows)."""
         assert block_ids.dim() == 2 and block_ids.dtype == torch.long
         ids = block_ids.to(self.device).contiguous()
         n_seq, bl = ids.shape
@@ -120,12 +122,16 @@ class LLaDAModel:
             assert tuple(km.shape) == (n_seq, seq_len)
         assert kv_cache.numel() >= self.lib.llada_kv_cache_bytes(C.byref(self._c_cfg), n_seq, seq_len)
         cos, sin = self.rope_tables(seq_len)
+        n_rows = n_seq * bl if logit_rows is None else int(logit_rows.numel())
+        if logit_rows is not None:
+            assert logit_rows.dtype == torch.int32 and logit_rows.is_contiguous() and logit_rows.device == ids.device
         if out is None:
-            out = torch.empty(n_seq * bl, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
+            out = torch.empty(n_rows, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
         ws = self._scratch("_ws_block", self.lib.llada_forward_block_workspace_bytes(C.byref(self._c_cfg), n_seq, seq_len, bl))
         _lib.check(self.lib.llada_forward_block(C.byref(self._c_cfg), C.byref(self._c_w), ids.data_ptr(), _lib.ptr(km),
                                                 cos.data_ptr(), sin.data_ptr(), n_seq, seq_len, block_start, bl,
-                                                kv_cache.data_ptr(), 1 if update_cache else 0, out.data_ptr(),
+                                                kv_cache.data_ptr(), 1 if update_cache else 0, _lib.ptr(logit_rows),
+                                                n_rows if logit_rows is not None else 0, out.data_ptr(),
                                                 ws.data_ptr(), ws.numel(),
                                                 _lib.stream_ptr()))
         return out

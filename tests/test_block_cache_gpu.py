@@ -216,7 +216,8 @@ def test_block_step_rejects_bad_arguments(lib, small):
         model.forward_block(ids, None, 32, 0, kv)             # cache too small for the sequence
 
 
-def test_generate_dual_cache_single_step_blocks_equal_uncached(lib, small):
+@pytest.mark.parametrize("cache", ["dual", "prefix"])
+def test_generate_dual_cache_single_step_blocks_equal_uncached(lib, small, cache):
     """One step per block: only full forwards run, so the cached sampler is the uncached one, bit for bit."""
     from llada_amd import generate
     ocfg, W = small
@@ -224,12 +225,43 @@ def test_generate_dual_cache_single_step_blocks_equal_uncached(lib, small):
     g = np.random.Generator(np.random.PCG64(8))
     prompt = torch.from_numpy(g.integers(0, MASK_ID, size=(2, 9), dtype=np.int64))
     a = generate(model, prompt, steps=4, gen_length=32, block_length=8, mask_id=MASK_ID)
-    b = generate(model, prompt, steps=4, gen_length=32, block_length=8, mask_id=MASK_ID, cache="dual")
+    b = generate(model, prompt, steps=4, gen_length=32, block_length=8, mask_id=MASK_ID, cache=cache)
     assert torch.equal(a, b)
 
 
+def test_prefix_cache_step_matches_oracle_and_row_subset_is_exact(lib, small):
+    """The "prefix" flavour of the cached step: everything from the block's start to the end of the sequence is
+    recomputed against the cached keys / values of the positions left of it (llada_forward_block with a range that
+    reaches the end, logits for the block's rows only).  Against the oracle's restatement (forward_block over the
+    same range) to the bf16 bound; the row subset gives exactly the rows of the all-rows call."""
+    ocfg, W = small
+    model = build(ocfg, W)
+    g = np.random.Generator(np.random.PCG64(12))
+    B, L, bs, bl = 2, 40, 16, 8
+    ids0 = g.integers(0, MASK_ID, size=(B, L), dtype=np.int64)
+    ids0[:, bs:] = MASK_ID
+    am = np.ones((B, L), dtype=np.int64)
+    am[1, :3] = 0
+    kv = model.kv_cache(B, L)
+    model.forward_rows(torch.from_numpy(ids0).cuda(), torch.from_numpy(am).cuda(), None, kv_cache=kv)
+    okv = []
+    forward(W, ocfg, ids0, am, emulate_bf16=True, kv_out=okv)
+    ids1 = ids0.copy()
+    ids1[:, bs:bs + 3] = g.integers(0, MASK_ID, size=(B, 3))            # three positions of the block got revealed
+    tail = torch.from_numpy(ids1[:, bs:]).cuda()
+    rows = (torch.arange(B, dtype=torch.int32)[:, None] * (L - bs) + torch.arange(bl, dtype=torch.int32)[None, :]).reshape(-1).cuda()
+    mask_t = torch.from_numpy(am).cuda()
+    sub = model.forward_block(tail, mask_t, L, bs, kv, update_cache=False, logit_rows=rows.contiguous())
+    full = model.forward_block(tail, mask_t, L, bs, kv, update_cache=False)
+    assert tuple(sub.shape) == (B * bl, ocfg.vocab_size)
+    assert torch.equal(sub, full.reshape(B, L - bs, -1)[:, :bl].reshape(B * bl, -1))
+    ref = forward_block(W, ocfg, ids1[:, bs:], bs, okv, am, emulate_bf16=True)[:, :bl]
+    assert max_rel(sub.float().cpu().numpy().reshape(B, bl, -1), ref) <= 2e-2
+
+
+@pytest.mark.parametrize("cache", ["dual", "prefix"])
 @pytest.mark.parametrize("cfg_scale,remasking", [(0.0, "low_confidence"), (1.0, "low_confidence"), (0.0, "random")])
-def test_generate_dual_cache_teacher_forced(lib, small, cfg_scale, remasking):
+def test_generate_dual_cache_teacher_forced(lib, small, cfg_scale, remasking, cache):
     """Every step of generate(cache='dual'): the oracle's epilogue on the logits the oracle's cached forward
     gives for that step's input must name the same transfers (given logits that agree to bf16 tolerance, checked
     through the confidences), exact transfer counts per step, monotone unmasking inside the current block."""
@@ -247,7 +279,7 @@ def test_generate_dual_cache_teacher_forced(lib, small, cfg_scale, remasking):
         trace.append((block, step, x.cpu().numpy().copy(), x0.cpu().numpy().copy(), conf.cpu().numpy().copy()))
 
     out = generate(model, torch.from_numpy(prompt), torch.from_numpy(am), steps=steps, gen_length=G, block_length=bl,
-                   cfg_scale=cfg_scale, remasking=remasking, mask_id=MASK_ID, step_callback=cb, cache="dual", seed=3)
+                   cfg_scale=cfg_scale, remasking=remasking, mask_id=MASK_ID, step_callback=cb, cache=cache, seed=3)
     out = out.cpu().numpy()
     assert np.array_equal(out[:, :P], prompt) and not (out == MASK_ID).any()
     x_in = np.full((B, P + G), MASK_ID, dtype=np.int64)
@@ -267,8 +299,12 @@ def test_generate_dual_cache_teacher_forced(lib, small, cfg_scale, remasking):
                 rows = (torch.arange(B, dtype=torch.int32, device="cuda")[:, None] * L
                         + torch.arange(bs, be, dtype=torch.int32, device="cuda")[None, :]).reshape(-1).contiguous()
                 lg = model.forward_rows(xt, full_mask, rows, kv_cache=kv2).reshape(B, bl, V)
-            else:
+            elif cache == "dual":
                 lg = model.forward_block(xt[:, bs:be], full_mask, L, bs, kv2).reshape(B, bl, V)
+            else:
+                crows = (torch.arange(B, dtype=torch.int32, device="cuda")[:, None] * (L - bs)
+                         + torch.arange(bl, dtype=torch.int32, device="cuda")[None, :]).reshape(-1).contiguous()
+                lg = model.forward_block(xt[:, bs:], full_mask, L, bs, kv2, update_cache=False, logit_rows=crows).reshape(B, bl, V)
             lg_full = np.zeros((B, L, V), dtype=np.float32)
             lg_full[:, bs:be] = lg.float().cpu().numpy()
             ox0, oconf = osamp.confidence_step(x_in, lg_full, MASK_ID, be, "low_confidence")
@@ -287,7 +323,7 @@ def test_generate_dual_cache_teacher_forced(lib, small, cfg_scale, remasking):
     assert np.array_equal(x_in, out)
     # determinism
     again = generate(model, torch.from_numpy(prompt), torch.from_numpy(am), steps=steps, gen_length=G, block_length=bl,
-                     cfg_scale=cfg_scale, remasking=remasking, mask_id=MASK_ID, cache="dual", seed=3).cpu().numpy()
+                     cfg_scale=cfg_scale, remasking=remasking, mask_id=MASK_ID, cache=cache, seed=3).cpu().numpy()
     assert np.array_equal(out, again)
 
 
