@@ -234,11 +234,9 @@ class LLaDAEvalHarness(_Base):
             mask = torch.zeros((len(group), P), dtype=torch.long)
             for r, i in enumerate(group):
                 n = len(prompts[i])
-                if n:
+                if n:                         # an empty prompt is all padding: the answer positions attend only each other
                     ids[r, P - n:] = torch.tensor(prompts[i], dtype=torch.long)
                     mask[r, P - n:] = 1
-                else:
-                    mask[r, :] = 1            # an empty prompt has nothing to pad against
             generated = generate(self.model, ids.to(self.device), mask.to(self.device), steps=self.steps,
                                  gen_length=self.gen_length, block_length=self.block_length, temperature=0,
                                  cfg_scale=self.cfg, remasking=self.remasking, mask_id=self.mask_id,
