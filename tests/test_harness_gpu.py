@@ -212,7 +212,7 @@ def test_batched_generate_until_reproduces_the_one_by_one_answers(lib):
     kw = dict(model=model, tokenizer=Tok(), mask_id=mask_id, batch_size=4, mc_num=8, steps=16, gen_length=16, block_length=8,
               seed=77, pad_id=3)
     questions = ["hello", "a considerably longer question than the others, with many more characters in it", "2+2=",
-                 "mid sized prompt here", "x", "another one of medium length!", "the quick brown fox jumps over"]
+                 "mid sized prompt here", "x", "another one of medium length!", "the quick brown fox jumps over", ""]
     reqs = [Req(q, {"until": ["q", "zz"]}) for q in questions]
     one_by_one = LLaDAEvalHarness(generate_batch_size=1, **kw).generate_until(reqs)
     batched = LLaDAEvalHarness(generate_batch_size=4, **kw).generate_until(reqs)
