@@ -79,11 +79,12 @@ def rope_tables(L, head_dim, theta):
 
 
 def apply_rope(t, cos, sin, emulate):
-    """t [B, H, L, D]; half-split rotation: (t1, t2) -> (t1*cos - t2*sin, t2*cos + t1*sin)."""
+    """t [B, H, L, D]; half-split rotation: (t1, t2) -> (t1*cos - t2*sin, t2*cos + t1*sin).  cos / sin [L, D/2]
+    (the same positions for every sequence) or [B, L, D/2] (one table row per token: explicit positions)."""
     half = t.shape[-1] // 2
     t1, t2 = t[..., :half], t[..., half:]
-    c = cos[None, None, :, :]
-    s = sin[None, None, :, :]
+    c = cos[None, None, :, :] if cos.ndim == 2 else cos[:, None, :, :]
+    s = sin[None, None, :, :] if sin.ndim == 2 else sin[:, None, :, :]
     out = np.concatenate([t1 * c - t2 * s, t2 * c + t1 * s], axis=-1).astype(np.float32)
     return _r(out, emulate)
 
@@ -127,14 +128,24 @@ def block(x, Wl, cfg, cos, sin, attention_mask=None, emulate_bf16=True, kv_out=N
 LAYER_KEYS = ("attn_norm", "q_proj", "k_proj", "v_proj", "attn_out", "ff_norm", "ff_proj", "up_proj", "ff_out")
 
 
-def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, return_hidden=False, kv_out=None):
+def positions_from_mask(attention_mask):
+    """Rotary positions counted from every row's first attended token: cumsum(mask) - 1, clamped at 0."""
+    m = (np.asarray(attention_mask) != 0).astype(np.int64)
+    return np.maximum(np.cumsum(m, axis=-1) - 1, 0)
+
+
+def forward(W, cfg, ids, attention_mask=None, emulate_bf16=True, n_layers=None, return_hidden=False, kv_out=None,
+            position_ids=None):
     """ids int64 [B, L] -> logits float32 [B, L, V] (bf16 values when emulate_bf16).  ``kv_out`` (a list)
-    receives every layer's rotated keys and values (k, v), each [B, H, L, D], for forward_block."""
+    receives every layer's rotated keys and values (k, v), each [B, H, L, D], for forward_block.
+    ``position_ids`` int [B, L]: rotary position of every token (default: its column, as the reference's model)."""
     em = emulate_bf16
     ids = np.asarray(ids)
     B, L = ids.shape
     x = W["wte"][ids].astype(np.float32)                     # [B, L, d]
     cos, sin = rope_tables(L, cfg.head_dim, cfg.rope_theta)
+    if position_ids is not None:
+        cos, sin = cos[np.asarray(position_ids)], sin[np.asarray(position_ids)]      # [B, L, D/2]
     nl = cfg.n_layers if n_layers is None else n_layers
     for i in range(nl):
         p = f"blocks.{i}."

@@ -11,7 +11,7 @@ import torch
 from oracle import sampler as osamp
 from oracle.bf16 import ulp_distance
 from oracle.model import LLaDAConfig as OCfg
-from oracle.model import forward, init_weights
+from oracle.model import forward, init_weights, positions_from_mask
 
 V, MASK_ID = 512, 511      # the mask token is an ordinary word of this small vocabulary
 RULES = ["low_confidence", "high_confidence", "low_entropy", "high_entropy", "random"]
@@ -29,7 +29,9 @@ def run(n_iter, seed, verbose=False, built=None, cache=None):
     """Runs n_iter random cases; raises AssertionError (with the case description) on the first mismatch.
     Returns the worst forward max-relative error seen.  ``cache="dual"``: the block-cached sampler (an approximation
     of its own; its steps are replayed on a second cache with the calls generate() makes, so the epilogue and the
-    transfers are checked on bit-identical logits; only the block's positions are candidates there)."""
+    transfers are checked on bit-identical logits; only the block's positions are candidates there); ``"prefix"``: the
+    same with the block and everything right of it recomputed.  Padded cases of the uncached sampler number the
+    rotary positions from every row's first real token half of the time (generate(position_ids="from_mask"))."""
     from llada_amd import generate
     ocfg, W, model = built if built is not None else build_model()
     g = np.random.Generator(np.random.PCG64(seed))
@@ -53,6 +55,7 @@ def run(n_iter, seed, verbose=False, built=None, cache=None):
             for b in range(B):
                 am[b, : int(g.integers(0, max(1, P // 2)))] = 0
         L = P + G
+        own_positions = padded and cache is None and bool(g.integers(0, 2))
         noise_log, rand_log, trace = [], [], []
 
         def noise_fn(shape):
@@ -68,16 +71,20 @@ def run(n_iter, seed, verbose=False, built=None, cache=None):
         def cb(block, step, x, x0, conf):
             trace.append((block, x.cpu().numpy().copy(), x0.cpu().numpy().copy(), conf.cpu().numpy().copy()))
 
-        desc = f"it {it}: B={B} P={P} G={G} bl={bl} steps={steps} rule={rule} T={T} cfg={cfg_scale} padded={padded}"
+        desc = (f"it {it}: B={B} P={P} G={G} bl={bl} steps={steps} rule={rule} T={T} cfg={cfg_scale} padded={padded} "
+                f"own_positions={own_positions}")
         out = generate(model, torch.from_numpy(prompt), None if am is None else torch.from_numpy(am), steps=steps, gen_length=G,
                        block_length=bl, temperature=T, cfg_scale=cfg_scale, remasking=rule, mask_id=MASK_ID,
                        noise_fn=noise_fn if T else None, rand_fn=rand_fn if rule == "random" else None,
-                       step_callback=cb, cache=cache).cpu().numpy()
+                       step_callback=cb, cache=cache, position_ids="from_mask" if own_positions else None).cpu().numpy()
         kv2 = model.kv_cache(2 * B if cfg_scale > 0 else B, L) if cache else None
         assert np.array_equal(out[:, :P], prompt), desc
         # (the mask token is an ordinary word of this small vocabulary: the model may predict it, and such a
         # position then stays masked, in the reference as here, so "no mask token left" is not asserted)
         full_mask = None if am is None else np.concatenate([am, np.ones((B, G), np.int64)], 1)
+        opos = positions_from_mask(full_mask) if own_positions else None           # the oracle's numbering
+        pos1 = None if opos is None else torch.from_numpy(opos.astype(np.int32)).cuda()
+        pos2 = None if opos is None else torch.cat([pos1, pos1])
         x_in = np.full((B, L), MASK_ID, dtype=np.int64)
         x_in[:, :P] = prompt
         prompt_index = x_in != MASK_ID
@@ -89,6 +96,13 @@ def run(n_iter, seed, verbose=False, built=None, cache=None):
                 row_lo = 0 if (cache is None and bs_ > 0 and (x_in[:, :bs_] == MASK_ID).any()) else bs_
             rows = (np.arange(B)[:, None] * L + np.arange(row_lo, be_)[None, :]).reshape(-1).astype(np.int32)
             fm = None if full_mask is None else torch.from_numpy(full_mask).cuda()
+            ce_ = be_ if cache == "dual" else L          # cached steps recompute [bs_, ce_); logits for the block's rows
+
+            def cached_rows(n_seq):
+                if cache != "prefix":
+                    return None
+                return (torch.arange(n_seq, dtype=torch.int32)[:, None] * (ce_ - bs_)
+                        + torch.arange(be_ - bs_, dtype=torch.int32)[None, :]).reshape(-1).cuda().contiguous()
             lg = np.zeros((B, L, V), dtype=np.float32)
             if cfg_scale > 0:
                 un = np.where(prompt_index, MASK_ID, x_in)
@@ -96,21 +110,22 @@ def run(n_iter, seed, verbose=False, built=None, cache=None):
                 fm2 = torch.from_numpy(np.concatenate([full_mask, full_mask])).cuda()
                 rows2 = torch.from_numpy(np.concatenate([rows, rows + B * L])).cuda()
                 if cache and t % spb:
-                    got = model.forward_block(torch.from_numpy(both[:, bs_:be_]).cuda(), fm2, L, bs_, kv2,
-                                              update_cache=False).float().cpu().numpy()
+                    got = model.forward_block(torch.from_numpy(np.ascontiguousarray(both[:, bs_:ce_])).cuda(), fm2, L, bs_, kv2,
+                                              update_cache=False, logit_rows=cached_rows(2 * B)).float().cpu().numpy()
                 else:
-                    got = model.forward_rows(torch.from_numpy(both).cuda(), fm2, rows2, kv_cache=kv2).float().cpu().numpy()
+                    got = model.forward_rows(torch.from_numpy(both).cuda(), fm2, rows2, kv_cache=kv2,
+                                             position_ids=pos2).float().cpu().numpy()
                 lg.reshape(B * L, V)[rows] = osamp.cfg_combine(got[: rows.size], got[rows.size:], cfg_scale)
             else:
                 if cache and t % spb:
-                    got = model.forward_block(torch.from_numpy(x_in[:, bs_:be_]).cuda(), fm, L, bs_, kv2,
-                                              update_cache=False).float().cpu().numpy()
+                    got = model.forward_block(torch.from_numpy(np.ascontiguousarray(x_in[:, bs_:ce_])).cuda(), fm, L, bs_, kv2,
+                                              update_cache=False, logit_rows=cached_rows(B)).float().cpu().numpy()
                 else:
                     got = model.forward_rows(torch.from_numpy(x_in).cuda(), fm, torch.from_numpy(rows).cuda(),
-                                             kv_cache=kv2).float().cpu().numpy()
+                                             kv_cache=kv2, position_ids=pos1).float().cpu().numpy()
                 lg.reshape(B * L, V)[rows] = got
             if t == 0 and cfg_scale == 0:
-                ref = forward(W, ocfg, x_in, full_mask, emulate_bf16=True).reshape(B * L, V)[rows]
+                ref = forward(W, ocfg, x_in, full_mask, emulate_bf16=True, position_ids=opos).reshape(B * L, V)[rows]
                 rel = float(np.abs(got - ref).max() / np.abs(ref).max())
                 worst_rel = max(worst_rel, rel)
                 assert rel <= 2e-2, (desc, rel)

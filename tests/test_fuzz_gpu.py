@@ -38,3 +38,4 @@ def test_remask_random_cases(lib, seed):
 def test_generate_random_cases_block_cached(lib):
     from tests.fuzz_util import run
     assert run(25, 4, cache="dual") <= 2e-2
+    assert run(15, 6, cache="prefix") <= 2e-2

@@ -13,6 +13,7 @@ t0 = time.time()
 for seed in range(first, first + n_seeds):
     a = run(cases, seed, built=built)
     run(cases // 2, seed + 10000, built=built, cache="dual")
+    run(cases // 4, seed + 20000, built=built, cache="prefix")
     b = run_likelihood(cases, seed, built=built)
     c = run_attention(cases // 2, seed)
     run_gemm(cases, seed)
