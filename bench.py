@@ -9,7 +9,7 @@ N*B*G / (steps_total * time_per_step).
 
 `python bench.py --gpus N` launches its own N ranks (one process per GPU, RCCL) when no launcher has set
 WORLD_SIZE; under `python -m torch.distributed.run` it uses the ranks it is given.  `--total-batch T` switches to
-strong scaling: T prompts in all, dealt over the ranks (BASELINE configuration 3 is `--total-batch 64 --gen 512
+strong scaling: T prompts in all, dealt over the ranks (the 64-prompt strong-scaling configuration is `--total-batch 64 --gen 512
 --block 64`).
 
 Prints ONE JSON line (rank 0).  Extra objects:
@@ -44,7 +44,7 @@ def cpu_model_name():
 
 
 def cpu_baseline(cfg, seconds_budget=25.0):
-    """The reference's CPU path (BASELINE configuration 1: batch 1, gen_length 64, steps 64, block_length 32,
+    """The reference's CPU path (the CPU-runnable benchmark configuration: batch 1, gen_length 64, steps 64, block_length 32,
     temperature 0, low_confidence, P = 128 -> 192 tokens per forward) timed on this host: oracle/model_torch.py
     (torch-CPU restatement of the forward on all the threads torch has) + the oracle's numpy epilogue, full
     logits for every position as the reference computes them (generate.py:92).  Bounded sample: the first few
@@ -234,7 +234,7 @@ def epilogue_roofline(torch, lib, _lib, device, rows, V, mask_id):
 
 
 def other_configs(torch, generate, model, cfg, sync_all):
-    """The remaining BASELINE configurations on this one GPU, a few steps each (the headline `value` stays the
+    """The remaining benchmark configurations on this one GPU, a few steps each (the headline `value` stays the
     8-rows-per-GPU line): the 64-prompt batch on ONE GPU at the headline shape and at gen512/blk64 (the N = 1
     points of the strong-scaling runs), guidance + Gumbel noise at gen1024/blk128, and the likelihood."""
     from llada_amd import get_log_likelihood
@@ -321,7 +321,7 @@ def other_configs(torch, generate, model, cfg, sync_all):
 
 
 def likelihood_bench(args, torch, dist, model, cfg, world, rank, device, backend):
-    """BASELINE configuration 4: get_log_likelihood(mc_num=128, batch_size=32) on synthetic ids, the 32 rows of
+    """The likelihood benchmark configuration: get_log_likelihood(mc_num=128, batch_size=32) on synthetic ids, the 32 rows of
     every Monte Carlo iteration dealt over the ranks, one all-reduce of the per-iteration loss sums per call."""
     from llada_amd import get_log_likelihood
     gen = torch.Generator().manual_seed(4321)
@@ -630,7 +630,7 @@ def main():
             rec["other_configs"] = other_configs(torch, generate, model, cfg, sync_all)
         if world == 1 and not args.no_cpu_baseline:      # the host baseline is reported at N = 1 only
             rec["cpu_baseline"] = cpu_baseline(cfg)
-            # the same configuration on the HIP path (BASELINE configuration 1: batch 1, P = 128, gen_length 64,
+            # the same configuration on the HIP path (batch 1, P = 128, gen_length 64,
             # steps 64, block_length 32): a whole call, wall clock.  `value` above is another workload (8 rows per
             # GPU, gen_length 256); this is the like-for-like pair of the host number.
             p1 = prompt[:1, :128] if P >= 128 else prompt[:1]
