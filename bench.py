@@ -145,6 +145,32 @@ def window_start(W_, K_, steps_per_block, steps_total):
     return start if start >= W_ and start + K_ <= steps_total else W_
 
 
+def event_timed_steps(torch, generate, model, prompt, G, bl, W_, K_, **sampler):
+    """Seconds of GPU time for K_ consecutive steps of ONE uninterrupted generate() call (steps == gen_length), between
+    two HIP events recorded on the launch stream after step W_ and after step W_ + K_: no host synchronisation inside
+    the window, so the device never idles waiting for the host to refill its queue (a synchronize right before a short
+    window of 7 ms steps costs the window several ms of restart: queue refill and clock ramp)."""
+    kw = dict(temperature=0., cfg_scale=0., remasking="low_confidence")
+    kw.update(sampler)
+    W_ = window_start(W_, K_, bl, G)
+    ev = {}
+
+    def cb(block, step, x, x0, conf):
+        n = block * bl + step + 1
+        if n in (W_, W_ + K_):
+            ev[n] = torch.cuda.Event(enable_timing=True)
+            ev[n].record()
+            if n == W_ + K_:
+                raise _TimedWindowDone
+
+    try:
+        generate(model, prompt, None, steps=G, gen_length=G, block_length=bl, step_callback=cb, **kw)
+    except _TimedWindowDone:
+        pass
+    torch.cuda.synchronize()
+    return ev[W_].elapsed_time(ev[W_ + K_]) * 1e-3
+
+
 def timed_steps(generate, model, prompt, G, bl, W_, K_, sync_all, on_start=None, row_offset=0, attention_mask=None,
                 span_block=False, **sampler):
     """Runs generate() (steps == gen_length) and times K_ consecutive steps of it, after at least W_ untimed ones,
@@ -592,7 +618,8 @@ def main():
         if world == 1 and B != 1 and not args.no_latency:
             # the single-sequence configuration (batch 1, same gen_length / steps / block_length):
             # per-step latency of forward + epilogue
-            t1 = timed_steps(generate, model, prompt[:1], G, bl, W_, K_, sync_all, span_block=True)
+            t1_sync = timed_steps(generate, model, prompt[:1], G, bl, W_, K_, sync_all, span_block=True)
+            t1 = event_timed_steps(torch, generate, model, prompt[:1], G, bl, max(W_, 8), K_)
             s1 = t1 / K_
             # one sequence sits on the ridge: report it against both bounds.  Bytes = every weight matrix read once
             # (the LM head and the last layer's three late projections serve only the block's rows, but their
@@ -600,6 +627,10 @@ def main():
             w_bytes = 2.0 * cfg.linear_params()
             fl1 = 2.0 * L * lin + 2.0 * bl * (d * d + 3 * d * F) + 2.0 * bl * d * V + L * 4.0 * L * d * cfg.n_layers
             rec["latency_batch1"] = {"ms_per_step": round(1e3 * s1, 4), "tokens_per_s": round(G / (steps_total * s1), 2),
+                                     "timing": f"HIP events around {K_} steps inside one uninterrupted generate() call (window over a "
+                                               "block boundary); ms_per_step_sync_bracketed is the same window between host "
+                                               "synchronisations, which charges the short steps the device's restart after idling",
+                                     "ms_per_step_sync_bracketed": round(1e3 * t1_sync / K_, 4),
                                      "workload": f"1 prompt x P={P}, gen_length={G}, steps={steps_total}, block_length={bl}",
                                      "roofline": {"weights_GBps": round(w_bytes / s1 / 1e9, 1), "frac_hbm": round(w_bytes / s1 / 8e12, 4),
                                                   "tflops_executed": round(fl1 / 1e12, 3),
