@@ -280,6 +280,26 @@ struct GumbelPart {
     int pad;
 };
 
+// Float32 evaluation of the Gumbel-max score l - T log(-log u), u a float64 uniform in [0, 1).
+// w = -log u: for u < 1/2, -logf((float)u): (float)u carries 2^-24 relative error, i.e. 6e-8 absolute in the
+// logarithm, logf adds at most one ulp of a result of magnitude <= 37 (4e-6), and w >= 0.69, so w is good to about
+// 2^-22 relative; for u >= 1/2, 1 - u is exact in float64 (Sterbenz), its rounding to float32 is 2^-24 relative and
+// -log1pf(-(1 - u)) a couple of ulp: again about 2^-22 relative, however close u is to 1.  g = logf(w) then carries that
+// relative error as absolute error plus one ulp of |g| <= 37 (4e-6); T * g and the final subtraction round once each
+// (ulp of a magnitude below 128: 8e-6).  Together under 2.5e-5 (1 + T); PRESCREEN_ERR = 2.5e-4 leaves a factor of ten.
+// u == 0 gives -inf, like the float64 expression.  No contraction, no fast-math in this build: the value is a pure
+// function of its arguments.
+constexpr float PRESCREEN_ERR = 2.5e-4f;
+__device__ __forceinline__ float gumbel_score32(float l, float T, double u) {
+    float w;
+    if (u < 0.5) {
+        w = -logf((float)u);
+    } else {
+        w = -log1pf(-(float)(1.0 - u));
+    }
+    return l - T * logf(w);
+}
+
 __global__ void __launch_bounds__(RS_THREADS) remask_stream_gumbel_kernel(const llada_remask_args a, int splits, int cps,
                                                                           int ex0, int ex1, RowPart* __restrict__ parts,
                                                                           GumbelPart* __restrict__ gparts, int n_stream) {
@@ -315,32 +335,57 @@ __global__ void __launch_bounds__(RS_THREADS) remask_stream_gumbel_kernel(const 
     uint32_t k0, k1;
     philox_key(a.seed, LLADA_STREAM_GUMBEL, k0, k1);
     const double temp = (double)a.temperature;
+    // Float32 pre-screen.  The float64 score l - T log(-log u) decides the arg-max, and its two float64 logarithms are
+    // what this sweep costs; a float32 evaluation of the same expression is within PRESCREEN_ERR (1 + T) of it for every
+    // u in [0, 1) (-log u through log1p(-(1 - u)) above one half, where 1 - u is exact in float64; error budget in the
+    // comment of gumbel_score32), so an entry whose float32 score lies more than twice that bound under the largest
+    // float32 score the wave has seen -- this trip included -- is strictly worse in float64 than the entry that set it
+    // and cannot be the arg-max, nor tie with it.  Only the others (a handful per piece) are ranked in float64, with
+    // the same comparison and the same first-index rule as before: the result is the full float64 sweep's, bit for bit.
+    const float tf = a.temperature;
+    const float slack = 2.0f * PRESCREEN_ERR * (1.0f + fabsf(tf));
+    float wave_max = -INFINITY;
 #pragma unroll 1
-    for (int c = c_begin + tid; c < c_end; c += RS_THREADS) {
-        const u32x4 qv = rs_chunk(lc, lu, cfg1, c, -1, -1);
+    for (int cb = c_begin; cb < c_end; cb += RS_THREADS) {          // the same trips for every lane: the wave maximum needs all
+        const int c = cb + tid;
+        const bool active = c < c_end;
+        const int cl = active ? c : c_end - 1;
+        const u32x4 qv = rs_chunk(lc, lu, cfg1, cl, -1, -1);
         double u[8];
         if (a.noise) {
-            const double* np = a.noise + (size_t)r * V + (size_t)c * 8;
+            const double* np = a.noise + (size_t)r * V + (size_t)cl * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] = np[e];
         } else {
 #pragma unroll
             for (int h2 = 0; h2 < 4; ++h2) {
-                const Philox4 ph = philox4x32_10((uint32_t)(c * 4 + h2), (uint32_t)col, a.row_offset + (uint32_t)b, a.step,
+                const Philox4 ph = philox4x32_10((uint32_t)(cl * 4 + h2), (uint32_t)col, a.row_offset + (uint32_t)b, a.step,
                                                  k0, k1);
                 u[2 * h2] = u53(ph.v[0], ph.v[1]);
                 u[2 * h2 + 1] = u53(ph.v[2], ph.v[3]);
             }
         }
+        float l[8], s32[8];
+        float lane_max = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int v = c * 8 + e;
-            float l = (e & 1) ? bf16hi(qv[e >> 1]) : bf16lo(qv[e >> 1]);
-            if (eos_inf && v == a.eos_id) l = -INFINITY;
-            const double sc = (double)l - temp * log(-log(u[e]));    // same arg-max as exp(l) / (-log u) ** T
-            if (sc > bd.v || (sc == bd.v && v < bd.i)) {
-                bd.v = sc;
-                bd.i = v;
+            const int v = cl * 8 + e;
+            l[e] = (e & 1) ? bf16hi(qv[e >> 1]) : bf16lo(qv[e >> 1]);
+            if (eos_inf && v == a.eos_id) l[e] = -INFINITY;
+            s32[e] = active ? gumbel_score32(l[e], tf, u[e]) : -INFINITY;
+            lane_max = fmaxf(lane_max, s32[e]);                     // fmaxf drops a NaN score: such an entry never wins below either
+        }
+        wave_max = fmaxf(wave_max, wave_reduce_max(lane_max));
+        const float th = wave_max - slack;                          // -inf - slack = -inf: nothing is skipped while all scores are -inf
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (active && s32[e] >= th) {
+                const int v = cl * 8 + e;
+                const double sc = (double)l[e] - temp * log(-log(u[e]));    // same arg-max as exp(l) / (-log u) ** T
+                if (sc > bd.v || (sc == bd.v && v < bd.i)) {
+                    bd.v = sc;
+                    bd.i = v;
+                }
             }
         }
     }
