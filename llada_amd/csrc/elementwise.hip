@@ -83,6 +83,59 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const bf16_t* __restrict__
     }
 }
 
+// The same norm with one WAVE per row (four rows per 256-thread workgroup, d = 256 * 8 * MAXV exactly): a lane keeps the
+// chunks of the four threads tid = lane + 64 w of the kernel above, adds their squares in the same order, reduces each
+// of the four partial sums with the same butterfly and adds them as red[0..3] are added there, so every output bit
+// is the same; what changes is that a row's 8 * MAXV loads per lane are all in flight at once and no workgroup barrier
+// sits between a row's two passes.
+template <int MAXV>
+__global__ void __launch_bounds__(256) rmsnorm_wave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ out, int64_t n_rows, float eps,
+                                                           const int32_t* __restrict__ row_index) {
+    constexpr int d = 256 * 8 * MAXV;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int64_t src_row = row_index ? (int64_t)row_index[r] : r;
+    const u16x8* xp = (const u16x8*)(x + src_row * d);
+    u16x8 v[4][MAXV];
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) v[wv][i] = xp[lane + 64 * wv + 256 * i];
+    float tot = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf16_to_f32(v[wv][i][e]);
+                ss += f * f;
+            }
+        ss = wave_reduce_sum(ss);
+        tot = wv == 0 ? ss : tot + ss;
+    }
+    const float rs = rsqrtf(tot / (float)d + eps);
+    const u16x8* wp = (const u16x8*)w;
+    u16x8* op = (u16x8*)(out + r * d);
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * wv + 256 * i;
+            const u16x8 wvv = wp[c];
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xn = round_bf16(bf16_to_f32(v[wv][i][e]) * rs);
+                o[e] = f32_to_bf16(xn * bf16_to_f32(wvv[e]));
+            }
+            op[c] = o;
+        }
+}
+
 // ---- rotary embedding, natural head layout (pairs j, j+64), in place on Q and K -----------------
 __global__ void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cs, const float* __restrict__ sn,
                             int64_t n_tokens, int L, int H, const int* __restrict__ positions) {
@@ -132,7 +185,11 @@ __global__ void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict_
     }
 }
 
+int g_rmsnorm_wave = 1;   // test hook: 0 = the one-workgroup-per-row kernel at every width
+
 }  // namespace
+
+extern "C" void llada_rmsnorm_use_wave_kernel(int on) { g_rmsnorm_wave = on; }
 
 extern "C" int llada_gather_rows_bf16(const void* in, const int32_t* rows, void* out, int64_t n_rows, int32_t d,
                                       int64_t n_in, void* stream) {
@@ -161,6 +218,12 @@ extern "C" int llada_rmsnorm_bf16(const void* x, const void* w, void* out, int64
     LLADA_CHECK_ARG(x && w && out && n_rows > 0, "rmsnorm: bad argument");
     LLADA_CHECK_SUPPORTED(d % 8 == 0 && d <= 256 * 8 * 4, "rmsnorm: d=%d must be a multiple of 8 and <= 8192", d);
     const int grid = (int)(n_rows < 8192 ? n_rows : 8192);
+    if (g_rmsnorm_wave && d == 256 * 8 * 2 && n_rows < (1ll << 31)) {      // the LLaDA-8B width: one wave per row
+        hipLaunchKernelGGL(rmsnorm_wave_kernel<2>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, n_rows, eps, row_index);
+        LLADA_CHECK_LAUNCH("rmsnorm_wave_kernel");
+        return LLADA_OK;
+    }
     if (d <= 256 * 8 * 2)
         hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)w, (bf16_t*)out, n_rows, d, eps, row_index);
