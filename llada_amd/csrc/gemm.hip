@@ -1117,8 +1117,16 @@ inline double small_m_step_us(int mfr, int nfh) {
 inline double plan_cost(int64_t M, int N, int nk_total, int mfr, int nfh, int S) {
     const int bm = mfr * 32, bn = 128 * nfh;
     const int64_t items = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * S;
-    double cost = (double)((items + 255) / 256) * (8.0 + small_m_step_us(mfr, nfh) * (nk_total / S));
-    if (S > 1) cost += 4.0 + (double)S * M * N * 4 / 3.0e6;
+    const double rounds = (double)((items + 255) / 256);
+    // the K loops cannot finish before every weight byte has left HBM once (5.8 TB/s): binds at M <= 64, where 256
+    // items of a few K steps each would otherwise look free (MLP output at M = 32: 16 ranges 29.7 us, 8 ranges of the
+    // 128-column tile 26.5)
+    const double loop = fmax(rounds * small_m_step_us(mfr, nfh) * (nk_total / S), (double)N * nk_total * BK * 2 / 5.8e6);
+    double cost = rounds * 8.0 + loop;
+    // a split plan must win by 5 %: inside a forward its partial tiles and second pass cost a few microseconds more
+    // than in the isolated launches the model is fitted to (QKV at M = 192: 192 x 256 in 4 ranges 35.3 + 8.2 us in the
+    // step against 37 for unsplit 128 x 128 tiles, which the model had 1 us behind)
+    if (S > 1) cost = (cost + 4.0 + (double)S * M * N * 4 / 3.0e6) * 1.05;
     return cost;
 }
 
@@ -1342,6 +1350,38 @@ extern "C" void llada_gemm_assume_tiled(int on) { g_w_tiled = on; }
 extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
     g_band_m = band_m > 0 ? band_m : 8;
     g_remap = remap;
+}
+
+// Test hook (runs on the host only, no GPU needed): the launch plan llada_gemm_bf16 would use for this shape with a
+// split-K workspace of `workspace_bytes`: out = {tile rows, tile columns, K ranges, persistent form (0 / 1)}.
+extern "C" int llada_gemm_describe_plan(int64_t M, int32_t N, int32_t K, int32_t epilogue, size_t workspace_bytes,
+                                        int32_t* out) {
+    LLADA_CHECK_ARG(out && M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm_describe_plan: bad argument");
+    epilogue &= ~LLADA_GEMM_W_TILED;
+    g_slab_bytes = workspace_bytes;
+    int mfr = g_force_mfr ? g_force_mfr : pick_mfr(M, N, K);
+    int nfh = 2, splits = 0;
+    if (!g_force_mfr) {
+        const Plan pl = choose_small_m_plan(M, N, K, mfr);
+        if (pl.ng) {
+            out[0] = SM_BM; out[1] = 32 * pl.ng; out[2] = pl.splits; out[3] = 0;
+            return LLADA_OK;
+        }
+        if (pl.mfr) {
+            mfr = pl.mfr;
+            nfh = pl.nfh;
+            splits = pl.splits;
+        }
+    }
+    const int bm = mfr * 32;
+    const int64_t n_tiles = ((M + bm - 1) / bm) * ((N + 128 * nfh - 1) / (128 * nfh));
+    if (splits == 0) splits = pick_splits((int)n_tiles, K / BK, M, N, g_use_pipelined != 0);
+    const int nk = K / BK / splits;
+    const bool nt = g_use_pipelined == 1 && M <= 3 * 192 && mfr != 8;
+    const bool stream = mfr != 8 && nfh == 2 && splits == 1 && !nt && nk >= 4 && (nk & 1) == 0 &&
+                        (g_use_pipelined == 2 || (g_use_pipelined == 1 && epilogue == LLADA_EPI_SWIGLU && n_tiles >= 2 * g_stream_grid));
+    out[0] = bm; out[1] = 128 * nfh; out[2] = splits; out[3] = stream ? 1 : 0;
+    return LLADA_OK;
 }
 
 // Measurement hook (bench.py): while active, every launch of the GEMM with the chosen epilogue and M is
