@@ -26,6 +26,11 @@ constexpr int EPI_PARTIAL = 100;   // internal: float32 partial tile of a split-
 #ifndef LLADA_GEMM_DEBUG
 #define LLADA_GEMM_DEBUG 0
 #endif
+// Issue priority of the MFMA blocks (timing experiments): 1 = raised around every block (the shipped form), 0 = never,
+// 2 = waves 4-7 raised once before the loop and no flips.
+#ifndef LLADA_GEMM_PRIO
+#define LLADA_GEMM_PRIO 1
+#endif
 
 struct GemmParams {
     const bf16_t* A;
@@ -501,7 +506,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
 
     auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[NFH][2], int ha, int hb) {
         if (LLADA_GEMM_DEBUG & 4) return;
-        __builtin_amdgcn_s_setprio(1);
+        if (LLADA_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
                 for (int nf = 0; nf < NFH; ++nf)
                     acc[ha * HA + mf][hb * NFH + nf] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a[mf][ks], acc[ha * HA + mf][hb * NFH + nf], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (LLADA_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
 
     // A phase = [refill + LDS reads] barrier [MFMAs] barrier.  Waves 4-7 (the upper half of the tile
@@ -561,6 +566,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_pipelined_kernel(const 
     WAIT_END(2, 2);         // own reads done; A1(0), B1(0) landed: B0(1) A0(1) A1(1) B1(1) are younger
     BARRIER();
     if (wm == 1) BARRIER(); // stagger: the upper half runs one barrier behind
+    if (LLADA_GEMM_PRIO == 2 && wm == 1) __builtin_amdgcn_s_setprio(1);
 
     for (int t = 0; t < nk; t += 2) {
         // ---- even tile t: A0 in X, A1 -> Y ----
@@ -702,7 +708,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_stream_kernel(const Gem
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto mma = [&](const bf16x8 (&a)[HA][2], const bf16x8 (&b)[2][2], int ha, int hb) {
-        __builtin_amdgcn_s_setprio(1);
+        if (LLADA_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -711,7 +717,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_stream_kernel(const Gem
                 for (int nf = 0; nf < 2; ++nf)
                     acc[ha * HA + mf][hb * 2 + nf] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a[mf][ks], acc[ha * HA + mf][hb * 2 + nf], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (LLADA_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
 
 #define WAIT_END(n_b, n_a) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((n_b) * NB + (n_a) * (two_a ? 2 : 1)) : "memory")
@@ -750,6 +756,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_bf16_stream_kernel(const Gem
     WAIT_END(2, 2);
     BARRIER();
     if (wm == 1) BARRIER();  // stagger: the upper half runs one barrier behind
+    if (LLADA_GEMM_PRIO == 2 && wm == 1) __builtin_amdgcn_s_setprio(1);
 
     for (;;) {
         int ik = 2;          // next K tile to fetch, relative to the item the sources point at
