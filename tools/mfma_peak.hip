@@ -46,6 +46,22 @@ __global__ __launch_bounds__(512, 1) void peak_kernel(float* out, int iters) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+        } else if (MODE == 3) {   // mode 0 in snake order: consecutive MFMAs share one operand register
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = (i & 1) ? 3 - jj : jj;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+        } else if (MODE == 4) {   // mode 0 with both operands changing at every step (diagonal walk)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int j = (i + d) & 3;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
         } else {   // 12 x 32x32x16, registers only (same flops as mode 0)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -87,6 +103,8 @@ int main(int argc, char** argv) {
     hipMalloc(&out, 4);
     run<0, 0>("16x16x32 regs only", iters * 4, out);
     run<0, 1>("16x16x32 regs only, random", iters * 4, out);
+    run<3, 1>("16x16x32 random, snake order", iters * 4, out);
+    run<4, 1>("16x16x32 random, diagonal", iters * 4, out);
     run<2, 1>("32x32x16 regs only, random", iters * 4, out);
     run<1, 0>("16x16x32 + ds_read_b128", iters * 4, out);
     run<1, 1>("16x16x32 + ds_read_b128, rnd", iters * 4, out);
