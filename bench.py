@@ -105,6 +105,29 @@ def cpu_baseline(cfg, seconds_budget=25.0):
                        f"median step {t_step:.2f} s; 1 token per step")}
 
 
+def sample_clock_power(delay_s, out):
+    """Shader clock and socket power as the vendor tools report them, read once `delay_s` seconds from now (called on a
+    thread while a workload runs on the GPU).  Informational: the record carries them next to the roofline so that the
+    2.4 GHz peak can be compared with the clock the chip actually holds; every failure leaves the fields out."""
+    import re
+    import subprocess
+    time.sleep(delay_s)
+    try:
+        txt = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+        if m:
+            out["sclk_mhz"] = int(m.group(1))
+    except Exception:
+        pass
+    try:
+        txt = subprocess.run(["amd-smi", "metric", "--power"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"SOCKET_POWER:\s*(\d+)\s*W", txt)
+        if m:
+            out["socket_power_w"] = int(m.group(1))
+    except Exception:
+        pass
+
+
 def measured_ceilings(torch, device, M, N, K):
     """Yardsticks measured on this GPU next to the vendor peaks: the vendor library's bf16 GEMM
     (torch.matmul -> hipBLASLt) at the dominant kernel's shape, and a device-to-device copy.
@@ -538,8 +561,16 @@ def main():
         return time.perf_counter() - t0
 
     whole_call_s, whole_call_attempts = None, 0
+    under_load = {}
     if not args.no_whole_call:
+        sampler_thread = None
+        if rank == 0:      # clock and power a few seconds into the whole call (host-side tools, nothing on the GPU)
+            import threading
+            sampler_thread = threading.Thread(target=sample_clock_power, args=(3.0, under_load), daemon=True)
+            sampler_thread.start()
         whole_call_s, whole_call_attempts = run_whole_call(), 1
+        if sampler_thread is not None:
+            sampler_thread.join(timeout=30)
     tot_ms, n_s = C.c_double(0), C.c_int(0)
     lib.llada_gemm_profile_end(C.byref(tot_ms), C.byref(n_s))
     torch.cuda.synchronize()
@@ -611,6 +642,13 @@ def main():
             v_whole = total_rows * G / whole_call_s
             rec["whole_call_s"] = round(whole_call_s, 4)
             rec["whole_call_attempts"] = whole_call_attempts
+            if under_load:
+                rec["under_load"] = dict(under_load, note="rocm-smi / amd-smi 3 s into the whole call; the bf16 peak of "
+                                         "`roofline` is quoted at 2.4 GHz")
+                if under_load.get("sclk_mhz") and rec["roofline"].get("achieved"):
+                    peak_at = rec["roofline"]["peak"] * under_load["sclk_mhz"] / 2400.0
+                    rec["under_load"]["mfma_peak_at_sclk_tflops"] = round(peak_at, 1)
+                    rec["under_load"]["roofline_frac_at_sclk"] = round(rec["roofline"]["achieved"] / peak_at, 4)
             rec["value_from_whole_call"] = round(v_whole, 3)
             rec["whole_call_vs_value"] = round(v_whole / tokens_per_s, 4)
             rec["whole_call_check"] = "ok" if abs(v_whole / tokens_per_s - 1.0) <= 0.03 else "FAILED: differs from value by more than 3 %"
