@@ -89,7 +89,7 @@ SIGNATURES = {
 }
 # test hooks outside the public header
 _EXTRA = {"llada_rows_force_splits": (None, [C.c_int]), "llada_gemm_force_tile_rows": (None, [C.c_int]), "llada_gemm_use_pipelined": (None, [C.c_int]),
-          "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_force_tile_cols": (None, [C.c_int]), "llada_gemm_force_small_m": (None, [C.c_int]), "llada_gemm_stream_grid": (None, [C.c_int]), "llada_attn_force_variant": (None, [C.c_int]), "llada_attn_force_key_splits": (None, [C.c_int]), "llada_gemm_assume_tiled": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]), "llada_gemm_describe_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.POINTER(C.c_int32)]), "llada_rmsnorm_use_wave_kernel": (None, [C.c_int]),
+          "llada_gemm_force_splits": (None, [C.c_int]), "llada_gemm_force_tile_cols": (None, [C.c_int]), "llada_gemm_force_small_m": (None, [C.c_int]), "llada_gemm_stream_grid": (None, [C.c_int]), "llada_attn_force_variant": (None, [C.c_int]), "llada_attn_force_key_splits": (None, [C.c_int]), "llada_gemm_assume_tiled": (None, [C.c_int]), "llada_gemm_tile_walk": (None, [C.c_int, C.c_int]), "llada_gemm_last_plan": (None, [C.POINTER(C.c_int32)]), "llada_gemm_describe_plan": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.POINTER(C.c_int32)]), "llada_rmsnorm_use_wave_kernel": (None, [C.c_int]),
           "llada_gemm_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_longlong]),
           "llada_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)])}
 

@@ -988,6 +988,10 @@ int g_stream_grid = 256;  // workgroups of the persistent kernel (one per CU)
 int g_band_m = 8, g_remap = 1;  // tuning hooks for the block -> tile walk
 int g_force_splits = 0;   // test hook: > 0 forces the split count when a workspace is given
 thread_local size_t g_slab_bytes = 0;  // capacity of the caller's split-K workspace for the current call
+thread_local int g_last_plan[4] = {0, 0, 0, 0};   // test hook: {tile rows, tile columns, K ranges, persistent form} of the last main-kernel launch
+inline void note_plan(int rows, int cols, int splits, int stream_form) {
+    g_last_plan[0] = rows; g_last_plan[1] = cols; g_last_plan[2] = splits; g_last_plan[3] = stream_form;
+}
 
 // Split count for a launch that would leave CUs idle: estimated time = rounds * (fill/drain +
 // K steps) + the reduce pass, in microseconds at ~1.25 us per K step.
@@ -1027,6 +1031,7 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
                 return LLADA_ERR_HIP;
             }
         }
+        note_plan(BM, 128, q.splits, 0);
         hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI, 1, WNT>), dim3(grid), dim3(NTHREADS), lds, stream, q);
         LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
         return LLADA_OK;
@@ -1049,6 +1054,7 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
                 }
             }
             const int sgrid = grid < g_stream_grid ? grid : g_stream_grid;
+            note_plan(BM, 256, q.splits, 1);
             hipLaunchKernelGGL((gemm_bf16_stream_kernel<MFR, EPI>), dim3(sgrid), dim3(NTHREADS), stream_lds, stream, q);
             LLADA_CHECK_LAUNCH("gemm_bf16_stream_kernel");
             return LLADA_OK;
@@ -1065,6 +1071,7 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
                     return LLADA_ERR_HIP;
                 }
             }
+            note_plan(BM, 256, q.splits, 0);
             hipLaunchKernelGGL((gemm_bf16_pipelined_kernel<MFR, EPI, 2, WNT>), dim3(grid), dim3(NTHREADS), lds, stream, q);
             LLADA_CHECK_LAUNCH("gemm_bf16_pipelined_kernel");
             return LLADA_OK;
@@ -1079,6 +1086,7 @@ int launch_main(const GemmParams& q, int grid, hipStream_t stream) {
             return LLADA_ERR_HIP;
         }
     }
+    note_plan(BM, 256, q.splits, 0);
     hipLaunchKernelGGL((gemm_bf16_kernel<MFR, EPI>), dim3(grid), dim3(NTHREADS), lds, stream, q);
     LLADA_CHECK_LAUNCH("gemm_bf16_kernel");
     return LLADA_OK;
@@ -1239,6 +1247,7 @@ int launch_small_m_kernel(const GemmParams& q, int grid, hipStream_t stream) {
             return LLADA_ERR_HIP;
         }
     }
+    note_plan(SM_BM, 32 * NG, q.splits, 0);
     hipLaunchKernelGGL((gemm_bf16_small_m_kernel<NG, EPI>), dim3(grid), dim3(NTHREADS), SmallM<NG>::LDS_BYTES + LLADA_SM_TRACE * 8192, stream, q);
     LLADA_CHECK_LAUNCH("gemm_bf16_small_m_kernel");
     return LLADA_OK;
@@ -1357,6 +1366,11 @@ extern "C" void llada_gemm_assume_tiled(int on) { g_w_tiled = on; }
 extern "C" void llada_gemm_tile_walk(int band_m, int remap) {
     g_band_m = band_m > 0 ? band_m : 8;
     g_remap = remap;
+}
+
+// Test hook: the plan of the last main-kernel launch of this thread (what llada_gemm_describe_plan must have predicted).
+extern "C" void llada_gemm_last_plan(int32_t* out) {
+    for (int i = 0; i < 4; ++i) out[i] = g_last_plan[i];
 }
 
 // Test hook (runs on the host only, no GPU needed): the launch plan llada_gemm_bf16 would use for this shape with a

@@ -635,3 +635,28 @@ def test_gemm_rope_epilogue_with_explicit_positions(lib):
     # out-of-table positions are clamped, not read out of bounds
     wild = torch.full((1, pad + n), 10 ** 6, dtype=torch.int32).cuda()
     assert torch.isfinite(model(ids, mask, position_ids=wild).logits.float()).all()
+
+
+@pytest.mark.parametrize("M", [32, 192, 384, 1536, 3072])
+def test_gemm_describe_plan_matches_launch(lib, M):
+    """The host-only plan hook (pinned for the LLaDA-8B shapes by tests/test_gemm_plans_cpu.py) predicts the tile, the
+    split count and the persistent form that llada_gemm_bf16 then launches, for plain / rotary / SwiGLU / residual
+    epilogues at the model's projection shapes, with and without a split-K workspace."""
+    import ctypes as C
+    d, F = 4096, 12288
+    shapes = [(3 * d, d, 2), (d, d, 1), (2 * F, d, 3), (d, F, 1)]
+    cos = torch.zeros(M, 64, device="cuda")
+    for (N, K, epi) in shapes:
+        A = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+        W = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda")
+        R = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda") if epi == 1 else None
+        for ws_bytes in (0, 16 * M * 3 * d * 4):
+            if ws_bytes > (1 << 30):
+                ws_bytes = 0
+            ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device="cuda") if ws_bytes else None
+            want, got = (C.c_int32 * 4)(), (C.c_int32 * 4)()
+            assert lib.llada_gemm_describe_plan(M, N, K, epi | 0x100, ws_bytes, want) == 0
+            gemm(lib, A, W, epi=epi | 0x100, R=R, cos=cos if epi == 2 else None, sin=cos if epi == 2 else None,
+                 seq_len=M if epi == 2 else 0, out_cols=N // 2 if epi == 3 else None, workspace=ws)
+            lib.llada_gemm_last_plan(got)
+            assert tuple(got) == tuple(want), (M, N, K, epi, ws_bytes, tuple(got), tuple(want))
