@@ -54,3 +54,20 @@ def test_torch_cpu_forward_matches_numpy_oracle():
     full = mt.forward(Wt, cfg, torch.from_numpy(ids), None, "f32").float().numpy()
     assert np.array_equal(sub, full[:, [3, 7]])
     assert mt.pick_mode(d=256, rows=16) in ("bf16", "f32")
+
+
+def test_clock_power_sampler_is_harmless_without_the_tools(monkeypatch, tmp_path):
+    """The `under_load` fields of the bench record come from rocm-smi / amd-smi; on a machine without them (or
+    with tools that print something else) the sampler must leave the record alone, never raise."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {}
+    monkeypatch.setenv("PATH", str(tmp_path))          # no vendor tools on the path
+    bench.sample_clock_power(0.0, out)
+    assert out == {}
+    for name, text in (("rocm-smi", "GPU[0]\t\t: sclk clock level: 1: (1803Mhz)"), ("amd-smi", "        SOCKET_POWER: 1398 W")):
+        tool = tmp_path / name
+        tool.write_text("#!/bin/sh\necho '%s'\n" % text)
+        tool.chmod(0o755)
+    bench.sample_clock_power(0.0, out)
+    assert out == {"sclk_mhz": 1803, "socket_power_w": 1398}
